@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- stereopairs/s of the colour-transfer hot path on MI355X.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N>1 the
+driver launches one rank per GPU with torch.distributed.run.  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1]): methods.linear.color_transfer_between_images (Reinhard) on
+synthetic 1920x1080 float32 RGB pairs, inputs resident in HBM, `--pairs` pairs per step
+(one step = one ct_reinhard_f32 call: stats sweep over 2*pairs images, finishing kernel,
+apply sweep).  Frames shard across ranks (frame f -> rank f % world); per-frame Lab stats
+(the per-frame metrics record) are gathered with ONE RCCL all_gather at the end of the timed
+region.  `value` = all ranks' pairs / max-over-ranks wall time.
+
+Extra keys: `roofline` (dominant kernel, HIP events per launch), `cpu_baseline` (the numpy oracle
+of the same function, rank 0, N=1 only), `extra` (MK / Xiao / IDT rates, informational).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "color-transfer_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+H, W = 1080, 1920
+N_PIX = H * W
+PLANE_F32 = N_PIX * 3 * 4                    # 24 883 200 B
+ALGO_BYTES_PER_PAIR = 3 * PLANE_F32          # read target, read reference, write output
+HBM_PEAK = 8.0e12                            # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
+
+
+def synth_frames(frame_ids, device):
+    """SURVEY 8d synthetic inputs: rng = default_rng(1234 + frame); uniform float32 HWC."""
+    t = np.empty((len(frame_ids), H, W, 3), dtype=np.float32)
+    r = np.empty_like(t)
+    for i, f in enumerate(frame_ids):
+        rng = np.random.default_rng(1234 + f)
+        t[i] = rng.random((H, W, 3), dtype=np.float32)
+        r[i] = rng.random((H, W, 3), dtype=np.float32)
+    return torch.from_numpy(t).to(device), torch.from_numpy(r).to(device)
+
+
+def cpu_baseline(n_pairs=4):
+    """The numpy oracle (float64 port of methods.linear.color_transfer_between_images) on host cores."""
+    from oracle import linear as olin
+    rng = np.random.default_rng(1234)
+    t = rng.random((H, W, 3), dtype=np.float32)
+    r = rng.random((H, W, 3), dtype=np.float32)
+    olin.color_transfer_between_images(t[:270], r[:270])          # warm-up (quarter frame)
+    times = []
+    for _ in range(n_pairs):
+        t0 = time.perf_counter()
+        olin.color_transfer_between_images(t, r)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": 1.0 / med, "unit": "stereopairs/s", "cores": 1, "kind": "port",
+            "sample": "%d x 1080p pair, oracle.linear.color_transfer_between_images (numpy float64, single thread), "
+                      "median %.3f s/pair; host has %d cores" % (n_pairs, med, os.cpu_count() or 0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--pairs", type=int, default=4, help="stereopairs per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import ct_hip
+    import methods.linear as lin
+    ct_hip.lib()                                   # fail loudly if the HIP library is missing
+
+    B, K, Wm = args.pairs, args.steps, args.warmup
+    # frames owned by this rank: f % world == rank; a ring of `B` resident pairs is re-used every step
+    frame_ids = [rank + world * i for i in range(B)]
+    tgt, ref = synth_frames(frame_ids, device)
+    out = torch.empty_like(tgt)
+    metrics = torch.zeros((K, 2 * B, ct_hip.CT_LAB_STATS_STRIDE), dtype=torch.float64, device=device)
+    gathered = torch.empty((world,) + tuple(metrics.shape), dtype=torch.float64, device=device) if world > 1 else None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(Wm):
+        ct_hip.reinhard(tgt, ref, out=out, stats_out=metrics[0])
+    if world > 1:                                   # warm the communicator outside the timed region
+        dist.all_gather_into_tensor(gathered, metrics)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(K):
+        ct_hip.reinhard(tgt, ref, out=out, stats_out=metrics[i])
+    if world > 1:
+        dist.all_gather_into_tensor(gathered, metrics)      # the per-frame metric gather (RCCL over xGMI)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    pairs_total = B * K * world
+    value = pairs_total / dt
+
+    # ---- per-kernel roofline: HIP events around each launch group on the launch stream ----------
+    roof = None
+    extra = {}
+    if rank == 0:
+        both = torch.cat([tgt, ref], dim=0)
+        n_prof = min(K, 50)
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n_prof)]
+        for _ in range(3):
+            st = ct_hip.lab_stats(both)
+            ct_hip.reinhard_apply(tgt, st[:B], st[B:], out=out)
+        torch.cuda.synchronize()
+        for i in range(n_prof):
+            ev[i][0].record()
+            st = ct_hip.lab_stats(both)                 # moments_kernel<float,true> (+ finishing kernel)
+            ev[i][1].record()
+            ct_hip.reinhard_apply(tgt, st[:B], st[B:], out=out)   # reinhard_apply_kernel<float,false>
+            ev[i][2].record()
+        torch.cuda.synchronize()
+        t_stats = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
+        t_apply = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) * 1e-3
+        kern = {
+            "moments_kernel<float,true>": {"bytes": 2 * B * PLANE_F32, "t": t_stats},
+            "reinhard_apply_kernel<float,false>": {"bytes": 2 * B * PLANE_F32, "t": t_apply},
+        }
+        dom = max(kern, key=lambda k: kern[k]["t"])
+        ach = kern[dom]["bytes"] / kern[dom]["t"]
+        roof = {"bound": "hbm", "kernel": dom, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": ach / HBM_PEAK, "traffic": None,
+                "algorithmic_bytes_per_launch": kern[dom]["bytes"], "avg_launch_s": kern[dom]["t"],
+                "kernels": {k: {"GB/s": v["bytes"] / v["t"] / 1e9, "avg_launch_us": v["t"] * 1e6,
+                                "algorithmic_bytes_per_launch": v["bytes"]} for k, v in kern.items()},
+                "path": {"algorithmic_bytes_per_pair": ALGO_BYTES_PER_PAIR,
+                         "GB/s": ALGO_BYTES_PER_PAIR * value / world / 1e9,
+                         "frac_of_peak": ALGO_BYTES_PER_PAIR * value / world / HBM_PEAK}}
+
+        if not args.no_extra:
+            def rate(fn, n=10):
+                fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                return n / (time.perf_counter() - t0)
+            extra["mk_pairs_per_s_f64out_hostalgebra"] = rate(
+                lambda: lin.monge_kantorovitch_color_transfer_cuda(tgt[0], ref[0]))
+            extra["xiao_pairs_per_s_f64out_hostalgebra"] = rate(
+                lambda: lin.color_transfer_in_correlated_color_space_cuda(tgt[0], ref[0]))
+            try:
+                import methods.iterative as it
+                rots = it.draw_rotations(4, seed=0)
+                extra["idt_pairs_per_s_f64"] = rate(
+                    lambda: it.iterative_distribution_transfer_cuda(tgt[0], ref[0], rotations=rots), n=5)
+            except Exception as e:  # IDT is a later milestone; never hide the reason
+                extra["idt_pairs_per_s_f64"] = "unavailable: %s" % (e,)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        line = {
+            "metric": "stereopairs/s at 1920x1080 (methods.linear.color_transfer_between_images)",
+            "value": value, "unit": "stereopairs/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[1]: methods.linear.color_transfer_between_images (Reinhard) on "
+                                   "1920x1080 synthetic float32 RGB pairs, HBM-resident, float64 arithmetic",
+                       "pairs_per_step_per_gpu": B, "io_dtype": "float32", "height": H, "width": W,
+                       "sharding": "frame f -> rank f % world; one all_gather of per-frame Lab stats"},
+            "roofline": roof, "cpu_baseline": cpu, "extra": extra,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

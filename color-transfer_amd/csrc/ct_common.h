@@ -1,0 +1,119 @@
+// ct_common.h -- shared launch / reduction helpers for libct_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ct_hip.h"
+
+namespace ct {
+
+constexpr int kBlock = 256;        // 4 waves of 64
+constexpr int kWave = 64;
+constexpr int kMaxBlocksPerImage = 1024;
+// total workgroups a streaming launch aims for: 256 CUs x 8 (guide: cap ~2048, grid-stride the rest)
+constexpr int kTargetBlocks = 2048;
+
+inline int blocks_per_image(int64_t n_chunks, int n_images) {
+    int64_t want = (n_chunks + kBlock - 1) / kBlock;
+    int64_t cap = kTargetBlocks / (n_images > 0 ? n_images : 1);
+    if (cap < 8) cap = 8;
+    if (cap > kMaxBlocksPerImage) cap = kMaxBlocksPerImage;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+#define CT_CHECK_LAUNCH()                           \
+    do {                                            \
+        hipError_t e__ = hipGetLastError();         \
+        if (e__ != hipSuccess) return (int)e__;     \
+    } while (0)
+
+// ---- 4-pixel (12 element) vector I/O of interleaved HWC data -------------------------------
+// A lane owns 4 whole pixels = 48 B (f32) / 96 B (f64) of contiguous memory, fetched as
+// 16-byte vectors.  `vec` = the image base is 16-byte aligned (wave-uniform).
+template <typename T>
+__device__ __forceinline__ void load12(const T *p, bool vec, double (&v)[12]);
+
+template <>
+__device__ __forceinline__ void load12<float>(const float *p, bool vec, double (&v)[12]) {
+    if (vec) {
+        const float4 *q = reinterpret_cast<const float4 *>(p);
+        const float4 a = q[0], b = q[1], c = q[2];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) v[i] = p[i];
+    }
+}
+
+template <>
+__device__ __forceinline__ void load12<double>(const double *p, bool vec, double (&v)[12]) {
+    if (vec) {
+        const double2 *q = reinterpret_cast<const double2 *>(p);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const double2 a = q[i];
+            v[2 * i] = a.x;
+            v[2 * i + 1] = a.y;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) v[i] = p[i];
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void store12(T *p, bool vec, const T (&v)[12]);
+
+template <>
+__device__ __forceinline__ void store12<float>(float *p, bool vec, const float (&v)[12]) {
+    if (vec) {
+        float4 *q = reinterpret_cast<float4 *>(p);
+        q[0] = make_float4(v[0], v[1], v[2], v[3]);
+        q[1] = make_float4(v[4], v[5], v[6], v[7]);
+        q[2] = make_float4(v[8], v[9], v[10], v[11]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) p[i] = v[i];
+    }
+}
+
+template <>
+__device__ __forceinline__ void store12<double>(double *p, bool vec, const double (&v)[12]) {
+    if (vec) {
+        double2 *q = reinterpret_cast<double2 *>(p);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) q[i] = make_double2(v[2 * i], v[2 * i + 1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) p[i] = v[i];
+    }
+}
+
+// ---- deterministic block sum of NV doubles per thread ------------------------------------
+// wave: __shfl_down tree (fixed shape); block: 4 wave leaders through LDS, added in wave
+// order by thread 0.  Result valid in thread 0 only.
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double *lds /* [4][NV] */) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] += __shfl_down(v[i], off, kWave);
+    }
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wid = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) lds[wid * NV + i] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = ((lds[i] + lds[NV + i]) + lds[2 * NV + i]) + lds[3 * NV + i];
+    }
+}
+
+}  // namespace ct

@@ -1,0 +1,475 @@
+// linear.hip -- global statistical colour transfers on gfx950 (MI355X).
+//
+// Replaces the numpy/skimage sweeps of the reference's methods/linear.py:
+//   A1  rgb2lab + np.mean/np.std          (linear.py:25-26,33-36)  -> moments_kernel<T, true>
+//   A2  affine in Lab + lab2rgb           (linear.py:38-40)        -> reinhard_apply_kernel
+//   A3  np.mean + np.cov                  (linear.py:64-67,103-106)-> moments_kernel<T, false>
+//   A5  (x - mu_t) @ A + mu_r             (linear.py:80,122)       -> affine3x3_kernel
+//
+// All of them are single coalesced HBM sweeps: a lane owns 4 whole HWC pixels (48 B of
+// f32) per iteration, Lab never leaves registers, moments are reduced wave (__shfl_down)
+// -> LDS -> one partial per workgroup -> a tiny finishing kernel, in a fixed order, so
+// results are bitwise reproducible run to run (no float atomics).
+//
+// Moments use the shifted-data form with a common pivot K = value of pixel 0 of the image:
+// S1 = sum(x-K), S2 = sum((x-K)(x-K)^T) are plainly additive across lanes/workgroups, and
+// mean = K + S1/n, M2 = S2 - S1 S1^T / n is stable in float64 even for near-constant images.
+#include "ct_color.h"
+#include "ct_common.h"
+
+namespace ct {
+
+constexpr int kPartialStride = 12;  // doubles per workgroup partial (6 used for Lab, 9 for RGB cov)
+constexpr int kPivotStride = 4;
+
+struct WsLayout {
+    double *partials;  // [n_images][kMaxBlocksPerImage][kPartialStride]
+    double *pivots;    // [n_images][kPivotStride]
+    double *stats;     // [n_images][CT_RGB_STATS_STRIDE] (only the fused entries use it)
+};
+
+static size_t ws_bytes_for(int n_images) {
+    return (size_t)n_images * ((size_t)kMaxBlocksPerImage * kPartialStride + kPivotStride + CT_RGB_STATS_STRIDE) *
+           sizeof(double);
+}
+
+static WsLayout ws_carve(void *ws, int n_images) {
+    WsLayout l;
+    l.partials = reinterpret_cast<double *>(ws);
+    l.pivots = l.partials + (size_t)n_images * kMaxBlocksPerImage * kPartialStride;
+    l.stats = l.pivots + (size_t)n_images * kPivotStride;
+    return l;
+}
+
+// -------------------------------------------------------------------------------------------
+// A1 / A3: first and second moments of Lab (LAB=true, 6 sums) or RGB (LAB=false, 9 sums)
+// -------------------------------------------------------------------------------------------
+template <bool LAB>
+__device__ __forceinline__ void to_space(double r, double g, double b, double &x, double &y, double &z) {
+    if (LAB) {
+        double fx, fy, fz;
+        rgb_to_f(r, g, b, fx, fy, fz);
+        f_to_lab(fx, fy, fz, x, y, z);
+    } else {
+        x = r; y = g; z = b;
+    }
+}
+
+template <bool LAB>
+__device__ __forceinline__ void accumulate(double (&s)[LAB ? 6 : 9], const double (&k)[3], double x, double y,
+                                           double z) {
+    const double dx = x - k[0], dy = y - k[1], dz = z - k[2];
+    s[0] += dx; s[1] += dy; s[2] += dz;
+    if (LAB) {
+        s[3] = fma(dx, dx, s[3]); s[4] = fma(dy, dy, s[4]); s[5] = fma(dz, dz, s[5]);
+    } else {
+        s[3] = fma(dx, dx, s[3]); s[4] = fma(dx, dy, s[4]); s[5] = fma(dx, dz, s[5]);
+        s[6] = fma(dy, dy, s[6]); s[7] = fma(dy, dz, s[7]); s[8] = fma(dz, dz, s[8]);
+    }
+}
+
+// grid = (G, n_images). Images [0, n_first) live at base0, the rest at base1 (so that the
+// targets and references of a batch of pairs are swept by ONE launch).
+template <typename T, bool LAB>
+__global__ __launch_bounds__(kBlock) void moments_kernel(const T *__restrict__ base0, const T *__restrict__ base1,
+                                                         int n_first, int64_t n_pixels, double *__restrict__ partials,
+                                                         double *__restrict__ pivots) {
+    constexpr int NV = LAB ? 6 : 9;
+    __shared__ double lds[4 * NV];
+    const int img = blockIdx.y;
+    const T *p = (img < n_first) ? base0 + (size_t)img * n_pixels * 3 : base1 + (size_t)(img - n_first) * n_pixels * 3;
+    const bool vec = (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+
+    double k[3] = {0.0, 0.0, 0.0};
+    if (n_pixels > 0) to_space<LAB>((double)p[0], (double)p[1], (double)p[2], k[0], k[1], k[2]);
+
+    double s[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s[i] = 0.0;
+
+    const int64_t n_chunks = n_pixels >> 2;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x; c < n_chunks; c += stride) {
+        double v[12];
+        load12<T>(p + c * 12, vec, v);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double x, y, z;
+            to_space<LAB>(v[3 * q], v[3 * q + 1], v[3 * q + 2], x, y, z);
+            accumulate<LAB>(s, k, x, y, z);
+        }
+    }
+    // ragged tail (n_pixels % 4 pixels): lanes 0..2 of workgroup 0
+    if (blockIdx.x == 0) {
+        const int64_t px = (n_chunks << 2) + threadIdx.x;
+        if (threadIdx.x < 3 && px < n_pixels) {
+            double x, y, z;
+            to_space<LAB>((double)p[px * 3], (double)p[px * 3 + 1], (double)p[px * 3 + 2], x, y, z);
+            accumulate<LAB>(s, k, x, y, z);
+        }
+    }
+    block_sum<NV>(s, lds);
+    if (threadIdx.x == 0) {
+        double *dst = partials + ((size_t)img * kMaxBlocksPerImage + blockIdx.x) * kPartialStride;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) dst[i] = s[i];
+        if (blockIdx.x == 0) {
+            pivots[img * kPivotStride + 0] = k[0];
+            pivots[img * kPivotStride + 1] = k[1];
+            pivots[img * kPivotStride + 2] = k[2];
+        }
+    }
+}
+
+// grid = n_images, one workgroup each: adds the G partials in a fixed order and writes the record.
+template <bool LAB>
+__global__ __launch_bounds__(kBlock) void moments_finalize_kernel(const double *__restrict__ partials,
+                                                                  const double *__restrict__ pivots, int n_blocks,
+                                                                  int64_t n_pixels, double *__restrict__ stats) {
+    constexpr int NV = LAB ? 6 : 9;
+    __shared__ double lds[4 * NV];
+    const int img = blockIdx.x;
+    double s[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s[i] = 0.0;
+    for (int b = threadIdx.x; b < n_blocks; b += kBlock) {
+        const double *src = partials + ((size_t)img * kMaxBlocksPerImage + b) * kPartialStride;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s[i] += src[i];
+    }
+    block_sum<NV>(s, lds);
+    if (threadIdx.x == 0) {
+        const double n = (double)n_pixels;
+        const double *k = pivots + img * kPivotStride;
+        const double m0 = s[0] / n, m1 = s[1] / n, m2 = s[2] / n;  // mean of (x - K)
+        if (LAB) {
+            double *o = stats + (size_t)img * CT_LAB_STATS_STRIDE;
+            o[0] = k[0] + m0; o[1] = k[1] + m1; o[2] = k[2] + m2;
+            // population variance (np.std, ddof 0); clamp the cancellation residue of constant images
+            const double v0 = fma(-s[0], m0, s[3]) / n, v1 = fma(-s[1], m1, s[4]) / n, v2 = fma(-s[2], m2, s[5]) / n;
+            o[3] = sqrt(v0 > 0.0 ? v0 : (v0 == v0 ? 0.0 : v0));
+            o[4] = sqrt(v1 > 0.0 ? v1 : (v1 == v1 ? 0.0 : v1));
+            o[5] = sqrt(v2 > 0.0 ? v2 : (v2 == v2 ? 0.0 : v2));
+            o[6] = n; o[7] = 0.0;
+        } else {
+            double *o = stats + (size_t)img * CT_RGB_STATS_STRIDE;
+            o[0] = k[0] + m0; o[1] = k[1] + m1; o[2] = k[2] + m2;
+            const double d = n - 1.0;  // np.cov default ddof = 1
+            const double cxx = fma(-s[0], m0, s[3]) / d, cxy = fma(-s[0], m1, s[4]) / d, cxz = fma(-s[0], m2, s[5]) / d;
+            const double cyy = fma(-s[1], m1, s[6]) / d, cyz = fma(-s[1], m2, s[7]) / d, czz = fma(-s[2], m2, s[8]) / d;
+            o[3] = cxx; o[4] = cxy; o[5] = cxz;
+            o[6] = cxy; o[7] = cyy; o[8] = cyz;
+            o[9] = cxz; o[10] = cyz; o[11] = czz;
+            o[12] = n; o[13] = 0.0; o[14] = 0.0; o[15] = 0.0;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// A2: Reinhard apply.  Lab is affine in (fx,fy,fz), so "to Lab, scale/shift, back from Lab"
+// collapses into one affine map in the cube-root domain:
+//   fy' = sL fy + cy ;  fx' = fy' + sa (fx - fy) + ca ;  fz' = fy' - sb (fy - fz) - cb
+// -------------------------------------------------------------------------------------------
+struct ReinhardCoef {
+    double sL, sa, sb, cy, ca, cb;
+};
+
+__device__ __forceinline__ ReinhardCoef reinhard_coef(const double *st, const double *sr) {
+    ReinhardCoef c;
+    c.sL = sr[3] / st[3];  // sigma_r / sigma_t   (inf/nan on a constant target, like the reference)
+    c.sa = sr[4] / st[4];
+    c.sb = sr[5] / st[5];
+    c.cy = (fma(-16.0 - st[0], c.sL, sr[0]) + 16.0) * (1.0 / 116.0);
+    c.ca = fma(-st[1], c.sa, sr[1]) * (1.0 / 500.0);
+    c.cb = fma(-st[2], c.sb, sr[2]) * (1.0 / 200.0);
+    return c;
+}
+
+template <typename T, bool OUT_LAB>
+__device__ __forceinline__ void reinhard_pixel(const ReinhardCoef &c, double r, double g, double b, T &o0, T &o1,
+                                               T &o2) {
+    double fx, fy, fz;
+    rgb_to_f(r, g, b, fx, fy, fz);
+    const double gy = fma(c.sL, fy, c.cy);
+    const double gx = gy + fma(c.sa, fx - fy, c.ca);
+    const double gz = gy - fma(c.sb, fy - fz, c.cb);
+    if (OUT_LAB) {
+        double L, A, B;
+        f_to_lab(gx, gy, gz, L, A, B);
+        o0 = (T)L; o1 = (T)A; o2 = (T)B;
+    } else {
+        double R, G, Bc;
+        f_to_rgb(gx, gy, gz, R, G, Bc);
+        o0 = clip01<T>(R); o1 = clip01<T>(G); o2 = clip01<T>(Bc);
+    }
+}
+
+template <typename T, bool OUT_LAB>
+__global__ __launch_bounds__(kBlock) void reinhard_apply_kernel(const T *__restrict__ target,
+                                                                const double *__restrict__ stats_t,
+                                                                const double *__restrict__ stats_r, T *__restrict__ out,
+                                                                int64_t n_pixels) {
+    const int img = blockIdx.y;
+    const T *p = target + (size_t)img * n_pixels * 3;
+    T *o = out + (size_t)img * n_pixels * 3;
+    const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(o)) & 15) == 0;
+    const ReinhardCoef c = reinhard_coef(stats_t + (size_t)img * CT_LAB_STATS_STRIDE,
+                                         stats_r + (size_t)img * CT_LAB_STATS_STRIDE);
+    const int64_t n_chunks = n_pixels >> 2;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t ch = (int64_t)blockIdx.x * kBlock + threadIdx.x; ch < n_chunks; ch += stride) {
+        double v[12];
+        T w[12];
+        load12<T>(p + ch * 12, vec, v);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            reinhard_pixel<T, OUT_LAB>(c, v[3 * q], v[3 * q + 1], v[3 * q + 2], w[3 * q], w[3 * q + 1], w[3 * q + 2]);
+        store12<T>(o + ch * 12, vec, w);
+    }
+    if (blockIdx.x == 0) {
+        const int64_t px = (n_chunks << 2) + threadIdx.x;
+        if (threadIdx.x < 3 && px < n_pixels) {
+            T a, b, d;
+            reinhard_pixel<T, OUT_LAB>(c, (double)p[px * 3], (double)p[px * 3 + 1], (double)p[px * 3 + 2], a, b, d);
+            o[px * 3] = a; o[px * 3 + 1] = b; o[px * 3 + 2] = d;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// A5: out = (x - mu_t) @ A + mu_r, float64 arithmetic, unclipped
+// -------------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ __launch_bounds__(kBlock) void affine3x3_kernel(const TI *__restrict__ in, const double *__restrict__ coef,
+                                                           TO *__restrict__ out, int64_t n_pixels) {
+    const int img = blockIdx.y;
+    const TI *p = in + (size_t)img * n_pixels * 3;
+    TO *o = out + (size_t)img * n_pixels * 3;
+    const bool vin = (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+    const bool vout = (reinterpret_cast<uintptr_t>(o) & 15) == 0;
+    const double *cf = coef + (size_t)img * 16;
+    double A[9], mt[3], mr[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) A[i] = cf[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { mt[i] = cf[9 + i]; mr[i] = cf[12 + i]; }
+
+    auto px = [&](double r, double g, double b, TO &o0, TO &o1, TO &o2) {
+        const double d0 = r - mt[0], d1 = g - mt[1], d2 = b - mt[2];
+        // same order as a row-vector @ matrix product: sum over i of d_i A[i][j], then + mu_r
+        o0 = (TO)(fma(d2, A[6], fma(d1, A[3], d0 * A[0])) + mr[0]);
+        o1 = (TO)(fma(d2, A[7], fma(d1, A[4], d0 * A[1])) + mr[1]);
+        o2 = (TO)(fma(d2, A[8], fma(d1, A[5], d0 * A[2])) + mr[2]);
+    };
+    const int64_t n_chunks = n_pixels >> 2;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t ch = (int64_t)blockIdx.x * kBlock + threadIdx.x; ch < n_chunks; ch += stride) {
+        double v[12];
+        TO w[12];
+        load12<TI>(p + ch * 12, vin, v);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) px(v[3 * q], v[3 * q + 1], v[3 * q + 2], w[3 * q], w[3 * q + 1], w[3 * q + 2]);
+        store12<TO>(o + ch * 12, vout, w);
+    }
+    if (blockIdx.x == 0) {
+        const int64_t q = (n_chunks << 2) + threadIdx.x;
+        if (threadIdx.x < 3 && q < n_pixels) {
+            TO a, b, d;
+            px((double)p[q * 3], (double)p[q * 3 + 1], (double)p[q * 3 + 2], a, b, d);
+            o[q * 3] = a; o[q * 3 + 1] = b; o[q * 3 + 2] = d;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// host-side launchers
+// -------------------------------------------------------------------------------------------
+template <typename T>
+static int check_image_args(const T *p, int64_t n_pixels, int n_images) {
+    if (n_pixels < 0 || n_images < 0) return CT_E_BADARG;
+    if (n_images > 0 && n_pixels > 0 && p == nullptr) return CT_E_BADARG;
+    if (reinterpret_cast<uintptr_t>(p) % sizeof(T)) return CT_E_ALIGN;
+    return CT_OK;
+}
+
+static int check_ws(const void *ws, size_t ws_bytes, int n_images) {
+    if (ws == nullptr || (reinterpret_cast<uintptr_t>(ws) & 15)) return CT_E_WORKSPACE;
+    if (ws_bytes < ws_bytes_for(n_images)) return CT_E_WORKSPACE;
+    return CT_OK;
+}
+
+template <typename T, bool LAB>
+static int launch_moments(const T *base0, const T *base1, int n_first, int n_images, int64_t n_pixels,
+                          const WsLayout &l, double *stats, hipStream_t s) {
+    if (n_images == 0) return CT_OK;
+    const int G = blocks_per_image(n_pixels >> 2, n_images);
+    hipLaunchKernelGGL((moments_kernel<T, LAB>), dim3(G, n_images), dim3(kBlock), 0, s, base0, base1, n_first,
+                       n_pixels, l.partials, l.pivots);
+    CT_CHECK_LAUNCH();
+    hipLaunchKernelGGL((moments_finalize_kernel<LAB>), dim3(n_images), dim3(kBlock), 0, s, l.partials, l.pivots, G,
+                       n_pixels, stats);
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+}
+
+template <typename T, bool OUT_LAB>
+static int launch_reinhard_apply(const T *target, const double *st, const double *sr, T *out, int64_t n_pixels,
+                                 int batch, hipStream_t s) {
+    if (batch == 0 || n_pixels == 0) return CT_OK;
+    const int G = blocks_per_image(n_pixels >> 2, batch);
+    hipLaunchKernelGGL((reinhard_apply_kernel<T, OUT_LAB>), dim3(G, batch), dim3(kBlock), 0, s, target, st, sr, out,
+                       n_pixels);
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+}
+
+template <typename T>
+static int lab_stats_impl(const T *rgb, int64_t n_pixels, int n_images, double *stats, void *ws, size_t ws_bytes,
+                          void *stream) {
+    int rc = check_image_args(rgb, n_pixels, n_images);
+    if (rc) return rc;
+    if (n_images > 0 && stats == nullptr) return CT_E_BADARG;
+    if ((rc = check_ws(ws, ws_bytes, n_images))) return rc;
+    return launch_moments<T, true>(rgb, rgb, n_images, n_images, n_pixels, ws_carve(ws, n_images), stats,
+                                   (hipStream_t)stream);
+}
+
+template <typename T>
+static int rgb_meancov_impl(const T *rgb, int64_t n_pixels, int n_images, double *stats, void *ws, size_t ws_bytes,
+                            void *stream) {
+    int rc = check_image_args(rgb, n_pixels, n_images);
+    if (rc) return rc;
+    if (n_images > 0 && stats == nullptr) return CT_E_BADARG;
+    if ((rc = check_ws(ws, ws_bytes, n_images))) return rc;
+    return launch_moments<T, false>(rgb, rgb, n_images, n_images, n_pixels, ws_carve(ws, n_images), stats,
+                                    (hipStream_t)stream);
+}
+
+template <typename T>
+static int reinhard_impl(const T *target, const T *reference, T *out, int64_t n_pixels, int batch,
+                         double *stats_out, void *ws, size_t ws_bytes, void *stream) {
+    int rc = check_image_args(target, n_pixels, batch);
+    if (rc) return rc;
+    if ((rc = check_image_args(reference, n_pixels, batch))) return rc;
+    if ((rc = check_image_args(out, n_pixels, batch))) return rc;
+    if ((rc = check_ws(ws, ws_bytes, 2 * batch))) return rc;
+    if (batch == 0) return CT_OK;
+    const WsLayout l = ws_carve(ws, 2 * batch);
+    // one sweep over all 2*batch images; stats records [0,batch) = targets, [batch,2batch) = references
+    double *stats = stats_out ? stats_out : l.stats;
+    rc = launch_moments<T, true>(target, reference, batch, 2 * batch, n_pixels, l, stats, (hipStream_t)stream);
+    if (rc) return rc;
+    return launch_reinhard_apply<T, false>(target, stats, stats + (size_t)batch * CT_LAB_STATS_STRIDE, out, n_pixels,
+                                           batch, (hipStream_t)stream);
+}
+
+template <typename TI, typename TO>
+static int affine_impl(const TI *in, const double *coef, TO *out, int64_t n_pixels, int batch, void *stream) {
+    int rc = check_image_args(in, n_pixels, batch);
+    if (rc) return rc;
+    if ((rc = check_image_args(out, n_pixels, batch))) return rc;
+    if (batch > 0 && coef == nullptr) return CT_E_BADARG;
+    if (batch == 0 || n_pixels == 0) return CT_OK;
+    const int G = blocks_per_image(n_pixels >> 2, batch);
+    hipLaunchKernelGGL((affine3x3_kernel<TI, TO>), dim3(G, batch), dim3(kBlock), 0, (hipStream_t)stream, in, coef,
+                       out, n_pixels);
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+}
+
+}  // namespace ct
+
+// -------------------------------------------------------------------------------------------
+// C ABI (include/ct_hip.h)
+// -------------------------------------------------------------------------------------------
+extern "C" {
+
+int ct_abi_version(void) { return CT_ABI_VERSION; }
+
+const char *ct_error_string(int code) {
+    switch (code) {
+        case CT_OK: return "ok";
+        case CT_E_BADARG: return "bad argument (null pointer, negative size or unknown enum)";
+        case CT_E_WORKSPACE: return "workspace missing, misaligned or smaller than ct_workspace_bytes()";
+        case CT_E_ALIGN: return "image pointer not aligned to its element size";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown ct error";
+    }
+}
+
+size_t ct_workspace_bytes(int kind, int64_t n_pixels, int n_images) {
+    (void)n_pixels;
+    if (n_images < 0) return 0;
+    switch (kind) {
+        case CT_WS_LAB_STATS:
+        case CT_WS_RGB_MEANCOV: return ct::ws_bytes_for(n_images);
+        case CT_WS_REINHARD: return ct::ws_bytes_for(2 * n_images);
+        default: return 0;
+    }
+}
+
+int ct_lab_stats_f32(const float *rgb, int64_t n_pixels, int n_images, double *stats, void *ws, size_t ws_bytes,
+                     void *stream) {
+    return ct::lab_stats_impl<float>(rgb, n_pixels, n_images, stats, ws, ws_bytes, stream);
+}
+int ct_lab_stats_f64(const double *rgb, int64_t n_pixels, int n_images, double *stats, void *ws, size_t ws_bytes,
+                     void *stream) {
+    return ct::lab_stats_impl<double>(rgb, n_pixels, n_images, stats, ws, ws_bytes, stream);
+}
+
+int ct_reinhard_apply_f32(const float *target, const double *stats_t, const double *stats_r, float *out,
+                          int64_t n_pixels, int batch, void *stream) {
+    int rc = ct::check_image_args(target, n_pixels, batch);
+    if (rc) return rc;
+    if ((rc = ct::check_image_args(out, n_pixels, batch))) return rc;
+    if (batch > 0 && (!stats_t || !stats_r)) return CT_E_BADARG;
+    return ct::launch_reinhard_apply<float, false>(target, stats_t, stats_r, out, n_pixels, batch, (hipStream_t)stream);
+}
+int ct_reinhard_apply_f64(const double *target, const double *stats_t, const double *stats_r, double *out,
+                          int64_t n_pixels, int batch, void *stream) {
+    int rc = ct::check_image_args(target, n_pixels, batch);
+    if (rc) return rc;
+    if ((rc = ct::check_image_args(out, n_pixels, batch))) return rc;
+    if (batch > 0 && (!stats_t || !stats_r)) return CT_E_BADARG;
+    return ct::launch_reinhard_apply<double, false>(target, stats_t, stats_r, out, n_pixels, batch,
+                                                    (hipStream_t)stream);
+}
+int ct_reinhard_lab_f32(const float *target, const double *stats_t, const double *stats_r, float *out_lab,
+                        int64_t n_pixels, int batch, void *stream) {
+    int rc = ct::check_image_args(target, n_pixels, batch);
+    if (rc) return rc;
+    if ((rc = ct::check_image_args(out_lab, n_pixels, batch))) return rc;
+    if (batch > 0 && (!stats_t || !stats_r)) return CT_E_BADARG;
+    return ct::launch_reinhard_apply<float, true>(target, stats_t, stats_r, out_lab, n_pixels, batch,
+                                                  (hipStream_t)stream);
+}
+
+int ct_reinhard_f32(const float *target, const float *reference, float *out, int64_t n_pixels, int batch,
+                    double *stats_out, void *ws, size_t ws_bytes, void *stream) {
+    return ct::reinhard_impl<float>(target, reference, out, n_pixels, batch, stats_out, ws, ws_bytes, stream);
+}
+int ct_reinhard_f64(const double *target, const double *reference, double *out, int64_t n_pixels, int batch,
+                    double *stats_out, void *ws, size_t ws_bytes, void *stream) {
+    return ct::reinhard_impl<double>(target, reference, out, n_pixels, batch, stats_out, ws, ws_bytes, stream);
+}
+
+int ct_rgb_meancov_f32(const float *rgb, int64_t n_pixels, int n_images, double *stats, void *ws, size_t ws_bytes,
+                       void *stream) {
+    return ct::rgb_meancov_impl<float>(rgb, n_pixels, n_images, stats, ws, ws_bytes, stream);
+}
+int ct_rgb_meancov_f64(const double *rgb, int64_t n_pixels, int n_images, double *stats, void *ws, size_t ws_bytes,
+                       void *stream) {
+    return ct::rgb_meancov_impl<double>(rgb, n_pixels, n_images, stats, ws, ws_bytes, stream);
+}
+
+int ct_affine3x3_f32_f64(const float *in, const double *coef, double *out, int64_t n_pixels, int batch, void *stream) {
+    return ct::affine_impl<float, double>(in, coef, out, n_pixels, batch, stream);
+}
+int ct_affine3x3_f64_f64(const double *in, const double *coef, double *out, int64_t n_pixels, int batch,
+                         void *stream) {
+    return ct::affine_impl<double, double>(in, coef, out, n_pixels, batch, stream);
+}
+int ct_affine3x3_f32_f32(const float *in, const double *coef, float *out, int64_t n_pixels, int batch, void *stream) {
+    return ct::affine_impl<float, float>(in, coef, out, n_pixels, batch, stream);
+}
+
+}  // extern "C"

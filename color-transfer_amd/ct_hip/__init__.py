@@ -1,0 +1,205 @@
+"""ctypes binding of libct_hip.so (C ABI: include/ct_hip.h) + thin torch-tensor helpers.
+
+PyTorch is used here only as the device allocator / stream provider: every function
+takes CUDA (= HIP on ROCm) tensors, passes raw device pointers and the current HIP stream
+to the library and returns without synchronising.
+
+There is NO CPU fallback: importing works anywhere (so that `-m "not gpu"` tests can
+check the exported symbols), but the first compute call without the library or without a
+GPU raises.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libct_hip.so")
+
+CT_LAB_STATS_STRIDE = 8
+CT_RGB_STATS_STRIDE = 16
+CT_WS_LAB_STATS, CT_WS_RGB_MEANCOV, CT_WS_REINHARD, CT_WS_IDT = 0, 1, 2, 3
+
+_c_i64 = ctypes.c_int64
+_c_int = ctypes.c_int
+_c_p = ctypes.c_void_p
+_c_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); kept in one table so tests can check it against include/ct_hip.h
+SIGNATURES = {
+    "ct_abi_version": (_c_int, []),
+    "ct_error_string": (ctypes.c_char_p, [_c_int]),
+    "ct_workspace_bytes": (_c_sz, [_c_int, _c_i64, _c_int]),
+    "ct_lab_stats_f32": (_c_int, [_c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
+    "ct_lab_stats_f64": (_c_int, [_c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
+    "ct_reinhard_apply_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_int, _c_p]),
+    "ct_reinhard_apply_f64": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_int, _c_p]),
+    "ct_reinhard_lab_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_int, _c_p]),
+    "ct_reinhard_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
+    "ct_reinhard_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
+    "ct_rgb_meancov_f32": (_c_int, [_c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
+    "ct_rgb_meancov_f64": (_c_int, [_c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
+    "ct_affine3x3_f32_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_p]),
+    "ct_affine3x3_f64_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_p]),
+    "ct_affine3x3_f32_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class CtHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libct_hip.so (once). Raises loudly when it is missing -- there is no fallback."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise CtHipError(
+                        "HIP library %s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "or `make -C color-transfer_amd/csrc`; this package has no CPU fallback" % LIB_PATH)
+                handle = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(handle, name)  # AttributeError = ABI mismatch, also loud
+                    fn.restype = res
+                    fn.argtypes = args
+                _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise CtHipError("libct_hip: %s (code %d)" % (lib().ct_error_string(rc).decode(), rc))
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _require_cuda(*tensors):
+    for t in tensors:
+        if not t.is_cuda:
+            raise CtHipError("ct_hip needs device tensors (got %s); no CPU path exists" % t.device)
+        if not t.is_contiguous():
+            raise CtHipError("ct_hip needs contiguous HWC tensors")
+
+
+_ws_cache = {}
+
+
+def workspace(kind, n_pixels, n_images, device):
+    """Per-(device, stream) scratch buffer, grown on demand (never shrinks)."""
+    need = lib().ct_workspace_bytes(kind, n_pixels, n_images)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _as_batch(img):
+    """[H,W,3] or [B,H,W,3] -> ([B,H,W,3] view, had_batch_dim)."""
+    if img.dim() == 3:
+        return img.unsqueeze(0), False
+    if img.dim() == 4:
+        return img, True
+    raise CtHipError("expected [H,W,3] or [B,H,W,3], got %s" % (tuple(img.shape),))
+
+
+def _suffix(t):
+    if t.dtype == torch.float32:
+        return "f32"
+    if t.dtype == torch.float64:
+        return "f64"
+    raise CtHipError("unsupported dtype %s (float32/float64 only)" % t.dtype)
+
+
+def lab_stats(img):
+    """rgb2lab + mean/std (population) per image: returns float64 [B, 8] = mean[3], std[3], n, 0.
+    Replaces methods/linear.py:25-26,33-36."""
+    x, _ = _as_batch(img)
+    _require_cuda(x)
+    B, n = x.shape[0], x.shape[1] * x.shape[2]
+    stats = torch.empty((B, CT_LAB_STATS_STRIDE), dtype=torch.float64, device=x.device)
+    ws = workspace(CT_WS_LAB_STATS, n, B, x.device)
+    fn = getattr(lib(), "ct_lab_stats_" + _suffix(x))
+    check(fn(_ptr(x), n, B, _ptr(stats), _ptr(ws), ws.numel(), _stream()))
+    return stats
+
+
+def rgb_meancov(img):
+    """np.mean + np.cov (ddof 1) per image: float64 [B, 16] = mean[3], cov[9], n, 0,0,0.
+    Replaces methods/linear.py:64-67,103-106."""
+    x, _ = _as_batch(img)
+    _require_cuda(x)
+    B, n = x.shape[0], x.shape[1] * x.shape[2]
+    stats = torch.empty((B, CT_RGB_STATS_STRIDE), dtype=torch.float64, device=x.device)
+    ws = workspace(CT_WS_RGB_MEANCOV, n, B, x.device)
+    fn = getattr(lib(), "ct_rgb_meancov_" + _suffix(x))
+    check(fn(_ptr(x), n, B, _ptr(stats), _ptr(ws), ws.numel(), _stream()))
+    return stats
+
+
+def reinhard_apply(target, stats_t, stats_r, out=None, to_lab=False):
+    """Affine map in Lab + lab2rgb (methods/linear.py:38-40); stats stay on the device."""
+    x, _ = _as_batch(target)
+    _require_cuda(x, stats_t, stats_r)
+    B, n = x.shape[0], x.shape[1] * x.shape[2]
+    if out is None:
+        out = torch.empty_like(x)
+    if to_lab:
+        if x.dtype != torch.float32:
+            raise CtHipError("the Lab probe exists for float32 only")
+        fn = lib().ct_reinhard_lab_f32
+    else:
+        fn = getattr(lib(), "ct_reinhard_apply_" + _suffix(x))
+    check(fn(_ptr(x), _ptr(stats_t), _ptr(stats_r), _ptr(out), n, B, _stream()))
+    return out.view(target.shape)
+
+
+def reinhard(target, reference, out=None, stats_out=None):
+    """methods.linear.color_transfer_between_images on device tensors, B pairs per call
+    (same H x W for target and reference).  One stats sweep over all 2B images, a finishing
+    kernel, one apply sweep; no host synchronisation."""
+    x, _ = _as_batch(target)
+    r, _ = _as_batch(reference)
+    _require_cuda(x, r)
+    if x.shape != r.shape or x.dtype != r.dtype:
+        raise CtHipError("fused reinhard needs equal shapes/dtypes; use lab_stats + reinhard_apply otherwise")
+    B, n = x.shape[0], x.shape[1] * x.shape[2]
+    if out is None:
+        out = torch.empty_like(x)
+    ws = workspace(CT_WS_REINHARD, n, B, x.device)
+    fn = getattr(lib(), "ct_reinhard_" + _suffix(x))
+    if stats_out is not None:
+        _require_cuda(stats_out)
+        if stats_out.dtype != torch.float64 or stats_out.numel() < 2 * B * CT_LAB_STATS_STRIDE:
+            raise CtHipError("stats_out must be float64 with >= 2*B*8 elements")
+    sp = _ptr(stats_out) if stats_out is not None else ctypes.c_void_p(0)
+    check(fn(_ptr(x), _ptr(r), _ptr(out), n, B, sp, _ptr(ws), ws.numel(), _stream()))
+    return out.view(target.shape)
+
+
+def affine3x3(img, coef, out_dtype=torch.float64, out=None):
+    """out = (x - mu_t) @ A + mu_r per image; coef float64 [B,16] = A[9], mu_t[3], mu_r[3], 0.
+    Replaces methods/linear.py:80,122."""
+    x, _ = _as_batch(img)
+    _require_cuda(x, coef)
+    B, n = x.shape[0], x.shape[1] * x.shape[2]
+    if out is None:
+        out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    name = "ct_affine3x3_%s_%s" % (_suffix(x), _suffix(out))
+    if name not in SIGNATURES:
+        raise CtHipError("no kernel for %s" % name)
+    check(getattr(lib(), name)(_ptr(x), _ptr(coef), _ptr(out), n, B, _stream()))
+    return out.view(img.shape)

@@ -1,0 +1,107 @@
+/*
+ * ct_hip.h -- C ABI of libct_hip.so: MI355X (gfx950) kernels for the per-frame
+ * colour-transfer hot path of egorchistov/color-transfer.
+ *
+ * The reference is pure Python (numpy / scipy / scikit-image / torch) and has no
+ * native layer; each entry point below replaces the numpy expression(s) cited next
+ * to it (paths relative to the reference root).  A binding only needs ctypes (see
+ * INTEGRATION.md).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller, except where the name
+ *     says host; nothing is allocated, freed or synchronised inside (one exception:
+ *     none -- the workspace comes from the caller, sized by ct_workspace_bytes());
+ *   - every entry takes the hipStream_t to launch on (as void*; NULL = default stream)
+ *     and returns immediately after enqueueing (asynchronous, graph-capturable);
+ *   - images are interleaved HWC, C = 3, contiguous: pixel p of image b starts at
+ *     base + (b * n_pixels + p) * 3 elements;
+ *   - return value: 0 = CT_OK, negative = CT_E_* argument error, positive = hipError_t;
+ *   - all arithmetic is float64 internally; "_f32"/"_f64" name the I/O element type.
+ */
+#ifndef CT_HIP_H
+#define CT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CT_OK 0
+#define CT_E_BADARG (-1)     /* null pointer, negative size, unknown enum */
+#define CT_E_WORKSPACE (-2)  /* workspace too small / misaligned */
+#define CT_E_ALIGN (-3)      /* image base not aligned to its element size */
+
+#define CT_ABI_VERSION 1
+
+/* doubles per image in a stats record written by ct_lab_stats / ct_rgb_meancov */
+#define CT_LAB_STATS_STRIDE 8  /* mean[3], std[3] (population, ddof 0), n, 0           */
+#define CT_RGB_STATS_STRIDE 16 /* mean[3], cov[9] row-major (ddof 1), n, 0, 0, 0       */
+
+enum ct_workspace_kind {
+    CT_WS_LAB_STATS = 0, /* ct_lab_stats_*: n_images = number of images in the call    */
+    CT_WS_RGB_MEANCOV = 1,
+    CT_WS_REINHARD = 2,  /* ct_reinhard_*:  n_images = batch (pairs)                    */
+    CT_WS_IDT = 3        /* ct_idt_*:       n_images = batch (pairs)                    */
+};
+
+int ct_abi_version(void);
+/* Human readable text for a return code of this library (never NULL). */
+const char *ct_error_string(int code);
+/* Bytes of device workspace an entry of `kind` needs for `n_images` images of `n_pixels`. */
+size_t ct_workspace_bytes(int kind, int64_t n_pixels, int n_images);
+
+/* ---- A1: rgb2lab + np.mean/np.std  (methods/linear.py:25-26,33-36; skimage rgb2lab) ----
+ * For image i in [0, n_images): stats[i*8 ..] = {mean L,a,b ; std L,a,b (ddof 0) ; n ; 0}.
+ * Deterministic: fixed-shape tree reduction, no float atomics.                          */
+int ct_lab_stats_f32(const float *rgb, int64_t n_pixels, int n_images, double *stats,
+                     void *ws, size_t ws_bytes, void *stream);
+int ct_lab_stats_f64(const double *rgb, int64_t n_pixels, int n_images, double *stats,
+                     void *ws, size_t ws_bytes, void *stream);
+
+/* ---- A2: (lab - mu_t) * sigma_r / sigma_t + mu_r ; lab2rgb   (methods/linear.py:38-40) ----
+ * stats_t / stats_r: records written by ct_lab_stats (device memory, no host sync).
+ * out may alias target.  Output clipped to [0,1] like skimage's xyz2rgb.                */
+int ct_reinhard_apply_f32(const float *target, const double *stats_t, const double *stats_r,
+                          float *out, int64_t n_pixels, int batch, void *stream);
+int ct_reinhard_apply_f64(const double *target, const double *stats_t, const double *stats_r,
+                          double *out, int64_t n_pixels, int batch, void *stream);
+/* Same affine map but the result is left in Lab (parity probe for the 1e-4 Lab gate).   */
+int ct_reinhard_lab_f32(const float *target, const double *stats_t, const double *stats_r,
+                        float *out_lab, int64_t n_pixels, int batch, void *stream);
+
+/* ---- a1 fused: methods.linear.color_transfer_between_images (methods/linear.py:8-42) ----
+ * batch pairs per call: stats of all 2*batch images in one launch, finalize, apply.
+ * ws: ct_workspace_bytes(CT_WS_REINHARD, n_pixels, batch).
+ * stats_out: NULL, or device [2*batch][8] doubles receiving the Lab stats records
+ * (targets first, then references) -- the per-frame metrics a caller may gather.       */
+int ct_reinhard_f32(const float *target, const float *reference, float *out,
+                    int64_t n_pixels, int batch, double *stats_out, void *ws, size_t ws_bytes,
+                    void *stream);
+int ct_reinhard_f64(const double *target, const double *reference, double *out,
+                    int64_t n_pixels, int batch, double *stats_out, void *ws, size_t ws_bytes,
+                    void *stream);
+
+/* ---- A3: np.mean(axis=0) + np.cov(x.T)   (methods/linear.py:64-67,103-106) ----
+ * stats[i*16 ..] = {mean[3] ; cov[9] row-major, ddof 1 ; n ; 0 0 0}.                     */
+int ct_rgb_meancov_f32(const float *rgb, int64_t n_pixels, int n_images, double *stats,
+                       void *ws, size_t ws_bytes, void *stream);
+int ct_rgb_meancov_f64(const double *rgb, int64_t n_pixels, int n_images, double *stats,
+                       void *ws, size_t ws_bytes, void *stream);
+
+/* ---- A5: (x - mu_t) @ A + mu_r   (methods/linear.py:80,122) ----
+ * coef: device, 16 doubles per image: A[9] row-major such that out_j = sum_i (x_i-mu_t_i)*A[i][j]
+ * (pass T for MK, T.T for Xiao), mu_t[3], mu_r[3], pad.  No clipping (the reference does
+ * not clip either; the caller clamps, methods/__init__.py:30).                           */
+int ct_affine3x3_f32_f64(const float *in, const double *coef, double *out, int64_t n_pixels,
+                         int batch, void *stream);
+int ct_affine3x3_f64_f64(const double *in, const double *coef, double *out, int64_t n_pixels,
+                         int batch, void *stream);
+int ct_affine3x3_f32_f32(const float *in, const double *coef, float *out, int64_t n_pixels,
+                         int batch, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CT_HIP_H */

@@ -1,0 +1,223 @@
+"""GPU parity: HIP kernels (through the C ABI / the methods.* drop-in API) vs the reference goldens
+and vs the CPU oracle.  Tolerances (BASELINE.json north_star): Lab max-abs <= 1e-4 against the
+float64-input reference; here the float64 device arithmetic is held to far tighter bounds."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import lab as olab        # noqa: E402
+from oracle import linear as olin     # noqa: E402
+
+LAB_TOL = 1e-4          # the stated gate
+LAB_TIGHT = 2e-5        # what float32 I/O + float64 arithmetic actually achieves (f32 Lab ulp at 100 = 7.6e-6)
+
+
+@pytest.fixture(scope="module")
+def lin():
+    import methods.linear as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import ct_hip
+    ct_hip.lib()
+    return ct_hip
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def lab_err(rgb_a, rgb_b):
+    return np.abs(olab.rgb2lab(np.asarray(rgb_a, np.float64)) - olab.rgb2lab(np.asarray(rgb_b, np.float64))).max()
+
+
+@pytest.mark.parametrize("case", ["uniform", "graded"])
+def test_reinhard_small_vs_reference(golden_dir, lin, hip, case):
+    g = _g(golden_dir, "linear_small.npz")
+    t, r = g[case + "/target"], g[case + "/reference"]
+    # stats
+    st = hip.lab_stats(dev(t)).cpu().numpy()[0]
+    sr = hip.lab_stats(dev(r)).cpu().numpy()[0]
+    np.testing.assert_allclose(st[0:3], g[case + "/lab_mean_t"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(st[3:6], g[case + "/lab_std_t"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(sr[0:3], g[case + "/lab_mean_r"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(sr[3:6], g[case + "/lab_std_r"], rtol=0, atol=1e-9)
+    assert st[6] == t.shape[0] * t.shape[1]
+    # float32 in -> float32 out, clipped
+    out = lin.color_transfer_between_images(t, r)
+    assert out.dtype == np.float32 and out.shape == t.shape
+    assert out.min() >= 0 and out.max() <= 1
+    ref = g[case + "/reinhard"]
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1.5e-7)
+    assert lab_err(out, ref) <= LAB_TIGHT
+    # float64 in -> float64 out
+    out64 = lin.color_transfer_between_images(t.astype(np.float64), r.astype(np.float64))
+    assert out64.dtype == np.float64
+    np.testing.assert_allclose(out64, ref, rtol=0, atol=1e-10)
+    # Lab probe: the affine-transferred image before lab2rgb (methods/linear.py:38)
+    probe = hip.reinhard_apply(dev(t), hip.lab_stats(dev(t)), hip.lab_stats(dev(r)), to_lab=True).cpu().numpy()
+    assert np.abs(probe.astype(np.float64) - g[case + "/reinhard_lab"]).max() <= LAB_TIGHT
+
+
+@pytest.mark.parametrize("case", ["uniform", "graded"])
+def test_xiao_mk_small_vs_reference(golden_dir, lin, case):
+    g = _g(golden_dir, "linear_small.npz")
+    t, r = g[case + "/target"], g[case + "/reference"]
+    out = lin.color_transfer_in_correlated_color_space(t, r)
+    assert out.dtype == np.float64
+    np.testing.assert_allclose(out, g[case + "/xiao"], rtol=0, atol=1e-9)
+    for d in ("MK", "sqrt", "cholesky"):
+        out = lin.monge_kantorovitch_color_transfer(t, r, decomposition=d)
+        assert out.dtype == np.float64
+        np.testing.assert_allclose(out, g[case + "/mk_" + d], rtol=0, atol=1e-9)
+    with pytest.raises(ValueError):
+        lin.monge_kantorovitch_color_transfer(t, r, decomposition="nope")
+
+
+def test_rgb_meancov_vs_reference(golden_dir, hip):
+    g = _g(golden_dir, "linear_small.npz")
+    for case in ("uniform", "graded"):
+        s = hip.rgb_meancov(dev(g[case + "/target"])).cpu().numpy()[0]
+        np.testing.assert_allclose(s[0:3], g[case + "/rgb_mean_t"], rtol=0, atol=1e-13)
+        np.testing.assert_allclose(s[3:12].reshape(3, 3), g[case + "/rgb_cov_t"], rtol=0, atol=1e-13)
+
+
+def test_u8_256_vs_reference(golden_dir, lin):
+    g = _g(golden_dir, "linear_u8_256.npz")
+    t8, r8 = g["target_u8"], g["reference_u8"]
+    t, r = t8.astype(np.float32) / 255, r8.astype(np.float32) / 255
+    sl = (slice(None, None, 3), slice(None, None, 3))
+    out = lin.color_transfer_between_images(t, r)
+    np.testing.assert_allclose(out[sl], g["reinhard_s3"], rtol=0, atol=1.5e-7)
+    assert lab_err(out[sl], g["reinhard_s3"]) <= LAB_TIGHT
+    np.testing.assert_allclose(lin.color_transfer_in_correlated_color_space(t, r)[sl], g["xiao_s3"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(lin.monge_kantorovitch_color_transfer(t, r)[sl], g["mk_MK_s3"], rtol=0, atol=1e-9)
+    # uint8 frames go through img_as_float semantics (k/255 in float64)
+    out8 = lin.color_transfer_between_images(t8, r8)
+    assert out8.dtype == np.float64
+    np.testing.assert_allclose(out8[sl], lin.color_transfer_between_images(t8 / 255.0, r8 / 255.0)[sl], rtol=0, atol=0)
+
+
+def test_1080p_vs_reference_samples(golden_dir, lin, hip):
+    g = _g(golden_dir, "linear_1080p.npz")
+    rng = np.random.default_rng(int(g["seed"]))
+    t = rng.random((1080, 1920, 3), dtype=np.float32)
+    r = rng.random((1080, 1920, 3), dtype=np.float32)
+    assert hashlib.sha256(t.tobytes()).hexdigest() == str(g["target_sha256"])
+    idx = g["idx"]
+    st = hip.lab_stats(dev(t)).cpu().numpy()[0]
+    np.testing.assert_allclose(st[0:3], g["lab_mean_t"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(st[3:6], g["lab_std_t"], rtol=0, atol=1e-9)
+    out = lin.color_transfer_between_images(t, r).reshape(-1, 3)[idx]
+    np.testing.assert_allclose(out, g["reinhard_samples"], rtol=0, atol=1.5e-7)
+    assert lab_err(out, g["reinhard_samples"]) <= LAB_TIGHT
+    assert LAB_TIGHT < LAB_TOL
+    out = lin.monge_kantorovitch_color_transfer(t, r).reshape(-1, 3)[idx]
+    np.testing.assert_allclose(out, g["mk_MK_samples"], rtol=0, atol=1e-9)
+    out = lin.color_transfer_in_correlated_color_space(t, r).reshape(-1, 3)[idx]
+    np.testing.assert_allclose(out, g["xiao_samples"], rtol=0, atol=1e-9)
+
+
+def test_1080p_full_vs_oracle_and_properties(lin, hip):
+    """Full-size check against the oracle (every pixel) + size-independent properties."""
+    rng = np.random.default_rng(99)
+    t = rng.random((1080, 1920, 3), dtype=np.float32)
+    r = (rng.random((1080, 1920, 3), dtype=np.float32) * 0.6 + 0.2).astype(np.float32)
+    out = lin.color_transfer_between_images(t, r)
+    ref = olin.color_transfer_between_images(t, r)
+    assert np.abs(out - ref).max() <= 1.5e-7
+    assert lab_err(out, ref) <= LAB_TIGHT
+    # property: the transferred Lab image has exactly the reference's Lab mean/std
+    td, rd = dev(t), dev(r)
+    st, sr = hip.lab_stats(td), hip.lab_stats(rd)
+    probe = hip.reinhard_apply(td, st, sr, to_lab=True).cpu().numpy().reshape(-1, 3).astype(np.float64)
+    np.testing.assert_allclose(probe.mean(axis=0), sr.cpu().numpy()[0, 0:3], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(probe.std(axis=0), sr.cpu().numpy()[0, 3:6], rtol=0, atol=1e-5)
+    # property: identity when reference == target (up to the Lab toe constants not being exact inverses)
+    same = lin.color_transfer_between_images(t, t)
+    assert np.abs(same - t).max() <= 2e-6
+    # determinism: bitwise identical on a second run
+    assert np.array_equal(out, lin.color_transfer_between_images(t, r))
+    # MK property: output covariance == reference covariance, output mean == reference mean
+    mk = lin.monge_kantorovitch_color_transfer(t, r).reshape(-1, 3)
+    np.testing.assert_allclose(mk.mean(axis=0), r.reshape(-1, 3).astype(np.float64).mean(axis=0), rtol=0, atol=1e-10)
+    np.testing.assert_allclose(np.cov(mk.T), np.cov(r.reshape(-1, 3).astype(np.float64).T), rtol=0, atol=1e-10)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 2), (1, 3), (1, 5), (3, 5), (7, 9), (17, 31), (64, 63)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_ragged_sizes_vs_oracle(lin, shape, dtype):
+    rng = np.random.default_rng(shape[0] * 100 + shape[1])
+    t = rng.random(shape + (3,)).astype(dtype)
+    r = rng.random((5, 7, 3)).astype(dtype)          # different size than the target: allowed by the reference
+    out = lin.color_transfer_between_images(t, r)
+    assert out.dtype == dtype and out.shape == t.shape
+    if shape == (1, 1):
+        assert np.isnan(out).all()                   # sigma_t = 0 -> 0 * inf = nan, as in the reference
+        return
+    ref = olin.color_transfer_between_images(t, r)
+    assert np.abs(out - ref).max() <= (1.5e-7 if dtype == np.float32 else 1e-9)
+    mk = lin.monge_kantorovitch_color_transfer(r, r[::-1].copy())
+    np.testing.assert_allclose(mk, olin.monge_kantorovitch_color_transfer(r, r[::-1].copy()), rtol=0, atol=1e-9)
+
+
+def test_batched_misaligned_images(hip):
+    """n_pixels % 4 != 0 makes every odd image of a batch start off a 16-byte boundary."""
+    rng = np.random.default_rng(5)
+    t = rng.random((3, 5, 7, 3), dtype=np.float32)
+    r = rng.random((3, 5, 7, 3), dtype=np.float32)
+    out = hip.reinhard(dev(t), dev(r)).cpu().numpy()
+    for b in range(3):
+        ref = olin.color_transfer_between_images(t[b], r[b])
+        assert np.abs(out[b] - ref).max() <= 1.5e-7
+    st = hip.lab_stats(dev(t)).cpu().numpy()
+    for b in range(3):
+        m, s = olin.lab_stats(t[b])
+        np.testing.assert_allclose(st[b, 0:3], m, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(st[b, 3:6], s, rtol=0, atol=1e-10)
+
+
+def test_noncontiguous_runner_style_input(lin):
+    """Runner passes permuted CHW->HWC views (methods/__init__.py:21-22)."""
+    rng = np.random.default_rng(3)
+    t_chw = rng.random((3, 20, 30), dtype=np.float32)
+    r_chw = rng.random((3, 20, 30), dtype=np.float32)
+    t, r = t_chw.transpose(1, 2, 0), r_chw.transpose(1, 2, 0)
+    assert not t.flags.c_contiguous
+    out = lin.color_transfer_between_images(t, r)
+    ref = olin.color_transfer_between_images(t, r)
+    assert np.abs(out - ref).max() <= 1.5e-7
+
+
+def test_out_of_gamut_and_toe_values(lin):
+    """Exercise both branches of every piecewise function + the z<0 clamp + the [0,1] clip."""
+    t = np.zeros((4, 4, 3), dtype=np.float64)
+    vals = [0.0, 1e-4, 0.003, 0.04, 0.04045, 0.0405, 0.2, 0.5, 0.9, 1.0, 0.01, 0.02, 0.7, 0.33, 0.05, 0.8]
+    t[..., 0] = np.array(vals).reshape(4, 4)
+    t[..., 1] = np.array(vals[::-1]).reshape(4, 4)
+    t[..., 2] = np.array(vals).reshape(4, 4).T
+    r = np.zeros((4, 4, 3), dtype=np.float64)
+    r[..., 0] = np.linspace(0, 1, 16).reshape(4, 4)
+    r[..., 1] = 0.02
+    r[..., 2] = np.linspace(1, 0, 16).reshape(4, 4) ** 3
+    out = lin.color_transfer_between_images(t, r)
+    ref = olin.color_transfer_between_images(t, r)
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-9)
+    assert (out == 0).any() or (out == 1).any()     # the clip fired somewhere
+
+
+def test_empty_image(lin):
+    out = lin.color_transfer_between_images(np.zeros((0, 4, 3), np.float32), np.ones((2, 2, 3), np.float32))
+    assert out.shape == (0, 4, 3)
