@@ -58,12 +58,15 @@ __device__ __forceinline__ double srgb_to_linear(double c) {
 }
 
 // Lab f(): v > 0.008856 ? cbrt(v) : 7.787 v + 16/116
-__device__ __forceinline__ double lab_f(double v) {
+__device__ __forceinline__ double lab_f_cbrt(double v) {
     // seed r0 ~ v^-1/3 ; cbrt(v) = v r^2 with r^3 = 1/v
     const double r0 = (double)hw_exp2((-1.0f / 3.0f) * hw_log2((float)v));
     const double b = (v * r0) * r0;        // v r0^2
     const double e = b * r0;               // v r0^3 = (1+eps)^3
-    const double cb = b * fma(-2.0 / 3.0, e, 5.0 / 3.0);
+    return b * fma(-2.0 / 3.0, e, 5.0 / 3.0);
+}
+__device__ __forceinline__ double lab_f(double v) {
+    const double cb = lab_f_cbrt(v);
     const double lin = fma(7.787, v, 16.0 / 116.0);
     return (v > 0.008856) ? cb : lin;
 }
@@ -96,9 +99,17 @@ __device__ __forceinline__ void rgb_to_f(double r, double g, double b, double &f
     const double x = fma(lb, CT_M02, fma(lg, CT_M01, lr * CT_M00));
     const double y = fma(lb, CT_M12, fma(lg, CT_M11, lr * CT_M10));
     const double z = fma(lb, CT_M22, fma(lg, CT_M21, lr * CT_M20));
-    fx = lab_f(x);
-    fy = lab_f(y);
-    fz = lab_f(z);
+    // The linear toe (v <= 0.008856, i.e. L* < 8) is rare and spatially coherent: evaluate it
+    // only in waves where some lane needs it (wave-uniform branch, identical results).
+    fx = lab_f_cbrt(x);
+    fy = lab_f_cbrt(y);
+    fz = lab_f_cbrt(z);
+    const bool toe = !((x > 0.008856) & (y > 0.008856) & (z > 0.008856));   // also true for NaN
+    if (__builtin_amdgcn_ballot_w64(toe)) {
+        fx = (x > 0.008856) ? fx : fma(7.787, x, 16.0 / 116.0);
+        fy = (y > 0.008856) ? fy : fma(7.787, y, 16.0 / 116.0);
+        fz = (z > 0.008856) ? fz : fma(7.787, z, 16.0 / 116.0);
+    }
 }
 
 __device__ __forceinline__ void f_to_lab(double fx, double fy, double fz, double &L, double &a, double &b) {
@@ -110,7 +121,13 @@ __device__ __forceinline__ void f_to_lab(double fx, double fy, double fz, double
 // (fx, fy, fz) -> sRGB, unclipped (clip happens after the cast to the output type)
 __device__ __forceinline__ void f_to_rgb(double fx, double fy, double fz, double &r, double &g, double &b) {
     fz = (fz < 0.0) ? 0.0 : fz;            // lab2xyz: z < 0 -> 0 (NaN stays NaN)
-    const double x = lab_finv(fx), y = lab_finv(fy), z = lab_finv(fz);
+    double x = (fx * fx) * fx, y = (fy * fy) * fy, z = (fz * fz) * fz;
+    const bool toe = !((fx > 0.2068966) & (fy > 0.2068966) & (fz > 0.2068966));
+    if (__builtin_amdgcn_ballot_w64(toe)) {  // wave-uniform: the linear toe is rare
+        x = (fx > 0.2068966) ? x : fma(fx, 1.0 / 7.787, -(16.0 / 116.0) / 7.787);
+        y = (fy > 0.2068966) ? y : fma(fy, 1.0 / 7.787, -(16.0 / 116.0) / 7.787);
+        z = (fz > 0.2068966) ? z : fma(fz, 1.0 / 7.787, -(16.0 / 116.0) / 7.787);
+    }
     const double lr = fma(z, CT_I02, fma(y, CT_I01, x * CT_I00));
     const double lg = fma(z, CT_I12, fma(y, CT_I11, x * CT_I10));
     const double lb = fma(z, CT_I22, fma(y, CT_I21, x * CT_I20));

@@ -65,6 +65,36 @@ __device__ __forceinline__ void load12<double>(const double *p, bool vec, double
     }
 }
 
+// raw (unconverted) form, so that a chunk can be prefetched without paying for 12 doubles
+template <typename T>
+struct Raw12 {
+    T e[12];
+};
+
+template <typename T>
+__device__ __forceinline__ void load12_raw(const T *p, bool vec, Raw12<T> &r) {
+    constexpr int VE = 16 / sizeof(T);  // elements per 16-byte vector
+    typedef T vec_t __attribute__((ext_vector_type(VE)));
+    if (vec) {
+        const vec_t *q = reinterpret_cast<const vec_t *>(p);
+#pragma unroll
+        for (int i = 0; i < 12 / VE; ++i) {
+            const vec_t a = q[i];
+#pragma unroll
+            for (int j = 0; j < VE; ++j) r.e[i * VE + j] = a[j];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) r.e[i] = p[i];
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void unpack12(const Raw12<T> &r, double (&v)[12]) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) v[i] = (double)r.e[i];
+}
+
 template <typename T>
 __device__ __forceinline__ void store12(T *p, bool vec, const T (&v)[12]);
 

@@ -47,9 +47,11 @@ static WsLayout ws_carve(void *ws, int n_images) {
 template <bool LAB>
 __device__ __forceinline__ void to_space(double r, double g, double b, double &x, double &y, double &z) {
     if (LAB) {
+        // moments are taken of (fy, fx - fy, fy - fz); L = 116 fy - 16, a = 500 (fx - fy),
+        // b = 200 (fy - fz) are per-axis affine images of those, applied once in the finishing kernel
         double fx, fy, fz;
         rgb_to_f(r, g, b, fx, fy, fz);
-        f_to_lab(fx, fy, fz, x, y, z);
+        x = fy; y = fx - fy; z = fy - fz;
     } else {
         x = r; y = g; z = b;
     }
@@ -89,15 +91,21 @@ __global__ __launch_bounds__(kBlock) void moments_kernel(const T *__restrict__ b
 
     const int64_t n_chunks = n_pixels >> 2;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x; c < n_chunks; c += stride) {
+    // register double-buffer: the next chunk's loads are in flight while this one is converted
+    int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    Raw12<T> cur, nxt;
+    if (c < n_chunks) load12_raw<T>(p + c * 12, vec, cur);
+    for (; c < n_chunks; c += stride) {
+        if (c + stride < n_chunks) load12_raw<T>(p + (c + stride) * 12, vec, nxt);
         double v[12];
-        load12<T>(p + c * 12, vec, v);
+        unpack12<T>(cur, v);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             double x, y, z;
             to_space<LAB>(v[3 * q], v[3 * q + 1], v[3 * q + 2], x, y, z);
             accumulate<LAB>(s, k, x, y, z);
         }
+        cur = nxt;
     }
     // ragged tail (n_pixels % 4 pixels): lanes 0..2 of workgroup 0
     if (blockIdx.x == 0) {
@@ -144,12 +152,13 @@ __global__ __launch_bounds__(kBlock) void moments_finalize_kernel(const double *
         const double m0 = s[0] / n, m1 = s[1] / n, m2 = s[2] / n;  // mean of (x - K)
         if (LAB) {
             double *o = stats + (size_t)img * CT_LAB_STATS_STRIDE;
-            o[0] = k[0] + m0; o[1] = k[1] + m1; o[2] = k[2] + m2;
+            // (fy, fx-fy, fy-fz) -> (L, a, b): scale 116/500/200, offset -16/0/0
+            o[0] = fma(116.0, k[0] + m0, -16.0); o[1] = 500.0 * (k[1] + m1); o[2] = 200.0 * (k[2] + m2);
             // population variance (np.std, ddof 0); clamp the cancellation residue of constant images
             const double v0 = fma(-s[0], m0, s[3]) / n, v1 = fma(-s[1], m1, s[4]) / n, v2 = fma(-s[2], m2, s[5]) / n;
-            o[3] = sqrt(v0 > 0.0 ? v0 : (v0 == v0 ? 0.0 : v0));
-            o[4] = sqrt(v1 > 0.0 ? v1 : (v1 == v1 ? 0.0 : v1));
-            o[5] = sqrt(v2 > 0.0 ? v2 : (v2 == v2 ? 0.0 : v2));
+            o[3] = 116.0 * sqrt(v0 > 0.0 ? v0 : (v0 == v0 ? 0.0 : v0));
+            o[4] = 500.0 * sqrt(v1 > 0.0 ? v1 : (v1 == v1 ? 0.0 : v1));
+            o[5] = 200.0 * sqrt(v2 > 0.0 ? v2 : (v2 == v2 ? 0.0 : v2));
             o[6] = n; o[7] = 0.0;
         } else {
             double *o = stats + (size_t)img * CT_RGB_STATS_STRIDE;
@@ -217,14 +226,19 @@ __global__ __launch_bounds__(kBlock) void reinhard_apply_kernel(const T *__restr
                                          stats_r + (size_t)img * CT_LAB_STATS_STRIDE);
     const int64_t n_chunks = n_pixels >> 2;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t ch = (int64_t)blockIdx.x * kBlock + threadIdx.x; ch < n_chunks; ch += stride) {
+    int64_t ch = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    Raw12<T> cur, nxt;
+    if (ch < n_chunks) load12_raw<T>(p + ch * 12, vec, cur);
+    for (; ch < n_chunks; ch += stride) {
+        if (ch + stride < n_chunks) load12_raw<T>(p + (ch + stride) * 12, vec, nxt);
         double v[12];
         T w[12];
-        load12<T>(p + ch * 12, vec, v);
+        unpack12<T>(cur, v);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             reinhard_pixel<T, OUT_LAB>(c, v[3 * q], v[3 * q + 1], v[3 * q + 2], w[3 * q], w[3 * q + 1], w[3 * q + 2]);
         store12<T>(o + ch * 12, vec, w);
+        cur = nxt;
     }
     if (blockIdx.x == 0) {
         const int64_t px = (n_chunks << 2) + threadIdx.x;
