@@ -1,0 +1,472 @@
+// idt.hip -- Pitie iterative distribution transfer on gfx950 (MI355X).
+//
+// Replaces the numpy sweeps of the reference's methods/iterative.py:31-55 (per iteration):
+//   A6  d = r @ x.T, lo/hi over both images   (iterative.py:34-35,39-40) -> idt_minmax_kernel / fused in apply
+//   A7  np.histogram x2 per axis               (iterative.py:42-43)       -> idt_hist_kernel (LDS-binned atomics)
+//   A8  cumsum, normalise, np.interp (LUT f)   (iterative.py:45-51)       -> idt_lut_kernel
+//   A9  np.interp(d0r, edges[1:], f, left=0), solve, add (iterative.py:53-55) -> idt_apply_kernel
+//
+// Exactness contract (mirrors oracle/idt_oracle.c operation for operation; the library is
+// built with -ffp-contract=off, every fused op below is an explicit fma()):
+//   * projection  fma(r2,x2, fma(r1,x1, r0*x0)) in float64;
+//   * lo/hi are exact (order-independent integer atomics on an order-preserving key);
+//   * bin of x = the unique k with edges[k] <= x < edges[k+1] (last bin closed), edges[i] =
+//     i*step + lo, edges[bins] = hi -- numpy's estimate-then-correct rule lands on exactly this
+//     k, so the estimate may use a reciprocal multiply instead of numpy's division;
+//   * counts are integers (LDS + global integer atomics) -> order independent;
+//   * LUT and interpolation use IEEE float64 division and separate multiply/add like numpy.
+// Hence bin indices, counts, LUTs AND the float64 output are bitwise identical to the oracle.
+#include "ct_common.h"
+
+namespace ct {
+
+constexpr int kIdtMaxBins = 1024;   // 3*bins*16 B of LUT in LDS (48 KiB) per workgroup
+constexpr int kIdtBlock = 256;
+
+// ---- order-preserving key for float64 (atomicMax on u64; zero-initialised memory = "-inf") ----
+__device__ __forceinline__ unsigned long long f64_key(double x) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_f64(unsigned long long k) {
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+__device__ __forceinline__ double proj(const double *r, double x0, double x1, double x2) {
+    return fma(r[2], x2, fma(r[1], x1, r[0] * x0));
+}
+
+// per (pair, iteration) workspace record, all zero-initialised by one hipMemsetAsync per call
+struct IdtLayout {
+    unsigned long long *mm;  // [batch][n_iter][3][4] keys: max(-t) , max(t), max(-r), max(r)  (min via negation)
+    unsigned int *hist;      // [batch][n_iter][2][3][bins]
+    double *lut;             // [batch][n_iter][3][bins][2]  (f[j], slope[j])
+    double *par;             // [batch][n_iter][3][4]        (lo, hi, step, scale)
+    size_t zero_bytes;       // leading bytes (mm + hist) that must be zero at call start
+    size_t total_bytes;
+};
+
+static IdtLayout idt_layout(void *ws, int batch, int n_iter, int bins) {
+    IdtLayout l;
+    char *p = reinterpret_cast<char *>(ws);
+    size_t off = 0;
+    l.mm = reinterpret_cast<unsigned long long *>(p + off);
+    off += (size_t)batch * n_iter * 3 * 4 * sizeof(unsigned long long);
+    l.hist = reinterpret_cast<unsigned int *>(p + off);
+    off += (size_t)batch * n_iter * 2 * 3 * bins * sizeof(unsigned int);
+    off = (off + 15) & ~(size_t)15;
+    l.zero_bytes = off;
+    l.lut = reinterpret_cast<double *>(p + off);
+    off += (size_t)batch * n_iter * 3 * bins * 2 * sizeof(double);
+    l.par = reinterpret_cast<double *>(p + off);
+    off += (size_t)batch * n_iter * 3 * 4 * sizeof(double);
+    l.total_bytes = off;
+    return l;
+}
+
+// -------------------------------------------------------------------------------------------
+// A6 (initial): min/max of r_it @ x for it in [it0, it0 + n_rot) ; `which` = 0 target, 1 reference
+// grid = (G, batch)
+// -------------------------------------------------------------------------------------------
+template <typename T, int MAXROT>
+__global__ __launch_bounds__(kIdtBlock) void idt_minmax_kernel(const T *__restrict__ img, int64_t n, const double *__restrict__ rot,
+                                                               int n_iter, int it0, int n_rot, int which,
+                                                               unsigned long long *__restrict__ mm) {
+    __shared__ unsigned long long lds[4 * 6];
+    const int b = blockIdx.y;
+    const T *p = img + (size_t)b * n * 3;
+    for (int q = 0; q < n_rot; ++q) {   // n_rot <= 8 in practice; one sweep per rotation keeps registers low
+        const int it = it0 + q;
+        double r[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r[i] = rot[((size_t)b * n_iter + it) * 9 + i];
+        unsigned long long k[6] = {0, 0, 0, 0, 0, 0};
+        for (int64_t i = (int64_t)blockIdx.x * kIdtBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kIdtBlock) {
+            const double x0 = (double)p[3 * i], x1 = (double)p[3 * i + 1], x2 = (double)p[3 * i + 2];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double d = proj(r + 3 * j, x0, x1, x2);
+                const unsigned long long kn = f64_key(-d), kx = f64_key(d);
+                k[2 * j] = kn > k[2 * j] ? kn : k[2 * j];
+                k[2 * j + 1] = kx > k[2 * j + 1] ? kx : k[2 * j + 1];
+            }
+        }
+        // mm[b][it][j][which*2 + {0: max(-d), 1: max(d)}]: gather the 6 keys into that layout
+        unsigned long long *dst = mm + (((size_t)b * n_iter + it) * 3) * 4;
+        // reorder: k = {j0min,j0max,j1min,j1max,j2min,j2max} -> dst[j*4 + which*2 + m]
+        __syncthreads();
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const unsigned long long o = __shfl_down(k[i], off, kWave);
+                k[i] = o > k[i] ? o : k[i];
+            }
+        }
+        const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x >> 6;
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) lds[wid * 6 + i] = k[i];
+        }
+        __syncthreads();
+        if (threadIdx.x < 6) {
+            unsigned long long m = lds[threadIdx.x];
+            for (int w = 1; w < kIdtBlock / kWave; ++w) {
+                const unsigned long long o = lds[w * 6 + threadIdx.x];
+                m = o > m ? o : m;
+            }
+            const int j = threadIdx.x >> 1, mmx = threadIdx.x & 1;
+            atomicMax(dst + j * 4 + which * 2 + mmx, m);
+        }
+    }
+}
+
+// decode lo/hi of (pair b, iteration it, axis j) from the key table; numpy widens lo == hi by 0.5
+__device__ __forceinline__ void idt_range(const unsigned long long *mm, int j, double &lo, double &hi) {
+    const unsigned long long *m = mm + j * 4;
+    const double tmin = -key_f64(m[0]), tmax = key_f64(m[1]), rmin = -key_f64(m[2]), rmax = key_f64(m[3]);
+    lo = tmin < rmin ? tmin : rmin;   // min(d0r[j].min(), d1r[j].min())
+    hi = tmax > rmax ? tmax : rmax;
+    if (lo == hi) { lo -= 0.5; hi += 0.5; }
+}
+
+__device__ __forceinline__ double idt_edge(int i, int bins, double lo, double hi, double step) {
+    return (i == bins) ? hi : ((double)i * step + lo);
+}
+
+// unique k with edges[k] <= x < edges[k+1] (last bin closed) == numpy's histogram bin
+__device__ __forceinline__ int idt_bin(double x, int bins, double lo, double hi, double step, double scale) {
+    int k = (int)((x - lo) * scale);
+    k = k < 0 ? 0 : (k > bins - 1 ? bins - 1 : k);
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        if (x < idt_edge(k, bins, lo, hi, step)) k -= (k > 0);
+        else if (k != bins - 1 && x >= idt_edge(k + 1, bins, lo, hi, step)) k += 1;
+    }
+    return k;
+}
+
+// -------------------------------------------------------------------------------------------
+// A8 part 1: publish (lo, hi, step, scale) of iteration `it` for the three axes. grid = batch, 64 threads
+// -------------------------------------------------------------------------------------------
+__global__ void idt_params_kernel(const unsigned long long *__restrict__ mm, double *__restrict__ par, int n_iter, int it,
+                                  int bins) {
+    const int b = blockIdx.x, j = threadIdx.x;
+    if (j < 3) {
+        double lo, hi;
+        idt_range(mm + (((size_t)b * n_iter + it) * 3) * 4, j, lo, hi);
+        double *o = par + (((size_t)b * n_iter + it) * 3 + j) * 4;
+        o[0] = lo; o[1] = hi; o[2] = (hi - lo) / (double)bins; o[3] = (double)bins / (hi - lo);
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// A7: histograms of both images on the three rotated axes. grid = (G, batch), dynamic LDS = 6*bins*4 B
+// -------------------------------------------------------------------------------------------
+template <typename TT, typename TR>
+__global__ __launch_bounds__(kIdtBlock) void idt_hist_kernel(const TT *__restrict__ tgt, int64_t n_t, const TR *__restrict__ ref,
+                                                             int64_t n_r, const double *__restrict__ rot,
+                                                             const double *__restrict__ par, int n_iter, int it, int bins,
+                                                             unsigned int *__restrict__ hist, unsigned short *__restrict__ binidx) {
+    extern __shared__ unsigned int lh[];  // [2][3][bins]
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < 6 * bins; i += kIdtBlock) lh[i] = 0;
+    double r[9], lo[3], hi[3], step[3], scale[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r[i] = rot[((size_t)b * n_iter + it) * 9 + i];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double *q = par + (((size_t)b * n_iter + it) * 3 + j) * 4;
+        lo[j] = q[0]; hi[j] = q[1]; step[j] = q[2]; scale[j] = q[3];
+    }
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * kIdtBlock;
+    const TT *pt = tgt + (size_t)b * n_t * 3;
+    for (int64_t i = (int64_t)blockIdx.x * kIdtBlock + threadIdx.x; i < n_t; i += stride) {
+        const double x0 = (double)pt[3 * i], x1 = (double)pt[3 * i + 1], x2 = (double)pt[3 * i + 2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int k = idt_bin(proj(r + 3 * j, x0, x1, x2), bins, lo[j], hi[j], step[j], scale[j]);
+            atomicAdd(&lh[j * bins + k], 1u);
+            if (binidx) binidx[(((size_t)b * n_iter + it) * 3 + j) * n_t + i] = (unsigned short)k;
+        }
+    }
+    const TR *pr = ref + (size_t)b * n_r * 3;
+    for (int64_t i = (int64_t)blockIdx.x * kIdtBlock + threadIdx.x; i < n_r; i += stride) {
+        const double x0 = (double)pr[3 * i], x1 = (double)pr[3 * i + 1], x2 = (double)pr[3 * i + 2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int k = idt_bin(proj(r + 3 * j, x0, x1, x2), bins, lo[j], hi[j], step[j], scale[j]);
+            atomicAdd(&lh[(3 + j) * bins + k], 1u);
+        }
+    }
+    __syncthreads();
+    unsigned int *gh = hist + ((size_t)b * n_iter + it) * 6 * bins;
+    for (int i = threadIdx.x; i < 6 * bins; i += kIdtBlock) {
+        const unsigned int c = lh[i];
+        if (c) atomicAdd(gh + i, c);
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// A8 part 2: cumulative histograms -> LUT f and its slopes. grid = (3, batch); dynamic LDS
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kIdtBlock) void idt_lut_kernel(const unsigned int *__restrict__ hist, const double *__restrict__ par,
+                                                            int n_iter, int it, int bins, double *__restrict__ lut) {
+    extern __shared__ double sm[];  // cp0[bins], cp1[bins], f[bins]
+    double *cp0 = sm, *cp1 = sm + bins, *f = sm + 2 * bins;
+    const int j = blockIdx.x, b = blockIdx.y;
+    const unsigned int *h0 = hist + (((size_t)b * n_iter + it) * 6 + j) * bins;
+    const unsigned int *h1 = hist + (((size_t)b * n_iter + it) * 6 + 3 + j) * bins;
+    const double *q = par + (((size_t)b * n_iter + it) * 3 + j) * 4;
+    const double lo = q[0], hi = q[1], step = q[2];
+    // exact integer prefix sums; two lanes walk the two histograms (<= 2048 bins: a few microseconds)
+    if (threadIdx.x < 2) {
+        const unsigned int *h = threadIdx.x ? h1 : h0;
+        double *cp = threadIdx.x ? cp1 : cp0;
+        unsigned long long c = 0;
+        for (int i = 0; i < bins; ++i) { c += h[i]; cp[i] = (double)c; }
+    }
+    __syncthreads();
+    const double t0 = cp0[bins - 1], t1 = cp1[bins - 1];
+    __syncthreads();
+    for (int i = threadIdx.x; i < bins; i += kIdtBlock) { cp0[i] = cp0[i] / t0; cp1[i] = cp1[i] / t1; }
+    __syncthreads();
+    // f[i] = np.interp(cp0[i], cp1, edges[1:])
+    for (int i = threadIdx.x; i < bins; i += kIdtBlock) {
+        const double x = cp0[i];
+        const double xp_first = cp1[0], xp_last = cp1[bins - 1];
+        double res;
+        if (x != x) res = x;
+        else if (x > xp_last) res = idt_edge(bins, bins, lo, hi, step);      // right = fp[-1]
+        else if (x < xp_first) res = idt_edge(1, bins, lo, hi, step);        // left  = fp[0]
+        else {
+            int a = 0, e = bins;  // cp1[a] <= x ; e = first index known > x (or bins)
+            while (e - a > 1) {
+                const int mid = (a + e) >> 1;
+                if (cp1[mid] <= x) a = mid; else e = mid;
+            }
+            const double fa = idt_edge(a + 1, bins, lo, hi, step);
+            if (a == bins - 1 || cp1[a] == x) res = fa;
+            else {
+                const double fb = idt_edge(a + 2, bins, lo, hi, step);
+                const double slope = (fb - fa) / (cp1[a + 1] - cp1[a]);
+                res = slope * (x - cp1[a]) + fa;
+                if (res != res) {
+                    res = slope * (x - cp1[a + 1]) + fb;
+                    if (res != res && fa == fb) res = fa;
+                }
+            }
+        }
+        f[i] = res;
+    }
+    __syncthreads();
+    double *o = lut + (((size_t)b * n_iter + it) * 3 + j) * bins * 2;
+    for (int i = threadIdx.x; i < bins; i += kIdtBlock) {
+        double slope = 0.0;
+        if (i < bins - 1) {
+            const double xa = idt_edge(i + 1, bins, lo, hi, step), xb = idt_edge(i + 2, bins, lo, hi, step);
+            slope = (f[i + 1] - f[i]) / (xb - xa);
+        }
+        o[2 * i] = f[i];
+        o[2 * i + 1] = slope;
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// A9 (+ next iteration's A6): d_r = interp(d0r, edges[1:], f, left=0); t += rinv @ (d_r - d0r)
+// grid = (G, batch); dynamic LDS = 3*bins*16 B
+// -------------------------------------------------------------------------------------------
+template <typename TT>
+__global__ __launch_bounds__(kIdtBlock) void idt_apply_kernel(const TT *__restrict__ tgt, double *__restrict__ out, int64_t n_t,
+                                                              const double *__restrict__ rot, const double *__restrict__ rinv,
+                                                              const double *__restrict__ par, const double *__restrict__ lut,
+                                                              int n_iter, int it, int bins, int round_f32,
+                                                              unsigned long long *__restrict__ mm) {
+    extern __shared__ double2 sl[];  // [3][bins] (f, slope)
+    __shared__ unsigned long long lds[4 * 6];
+    const int b = blockIdx.y;
+    {
+        const double2 *g = reinterpret_cast<const double2 *>(lut + ((size_t)b * n_iter + it) * 3 * bins * 2);
+        for (int i = threadIdx.x; i < 3 * bins; i += kIdtBlock) sl[i] = g[i];
+    }
+    double r[9], ri[9], rn[9], lo[3], hi[3], step[3], scale[3];
+    const bool has_next = (it + 1 < n_iter);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        r[i] = rot[((size_t)b * n_iter + it) * 9 + i];
+        ri[i] = rinv[((size_t)b * n_iter + it) * 9 + i];
+        rn[i] = has_next ? rot[((size_t)b * n_iter + it + 1) * 9 + i] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double *q = par + (((size_t)b * n_iter + it) * 3 + j) * 4;
+        lo[j] = q[0]; hi[j] = q[1]; step[j] = q[2]; scale[j] = q[3];
+    }
+    __syncthreads();
+    unsigned long long key[6] = {0, 0, 0, 0, 0, 0};
+    const TT *p = tgt + (size_t)b * n_t * 3;
+    double *o = out + (size_t)b * n_t * 3;
+    for (int64_t i = (int64_t)blockIdx.x * kIdtBlock + threadIdx.x; i < n_t; i += (int64_t)gridDim.x * kIdtBlock) {
+        const double x0 = (double)p[3 * i], x1 = (double)p[3 * i + 1], x2 = (double)p[3 * i + 2];
+        double delta[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double x = proj(r + 3 * j, x0, x1, x2);
+            double dr;
+            if (x != x) dr = x;
+            else if (x > hi[j]) dr = (double)bins;                         // right (cannot fire: x <= hi)
+            else if (x < idt_edge(1, bins, lo[j], hi[j], step[j])) dr = 0.0;  // left = 0: whole first bin -> 0
+            else {
+                const int k = idt_bin(x, bins, lo[j], hi[j], step[j], scale[j]);
+                const int jj = (x >= hi[j]) ? bins - 1 : k - 1;           // last j with edges[j+1] <= x
+                const double2 fs = sl[j * bins + jj];
+                const double xa = idt_edge(jj + 1, bins, lo[j], hi[j], step[j]);
+                if (jj == bins - 1 || xa == x) dr = fs.x;
+                else dr = fs.y * (x - xa) + fs.x;
+            }
+            if (round_f32) dr = (double)(float)dr;   // reference: d_r is float32 on iteration 0 for float32 input
+            delta[j] = dr - x;
+        }
+        const double y0 = proj(ri + 0, delta[0], delta[1], delta[2]) + x0;
+        const double y1 = proj(ri + 3, delta[0], delta[1], delta[2]) + x1;
+        const double y2 = proj(ri + 6, delta[0], delta[1], delta[2]) + x2;
+        o[3 * i] = y0; o[3 * i + 1] = y1; o[3 * i + 2] = y2;
+        if (has_next) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double d = proj(rn + 3 * j, y0, y1, y2);
+                const unsigned long long kn = f64_key(-d), kx = f64_key(d);
+                key[2 * j] = kn > key[2 * j] ? kn : key[2 * j];
+                key[2 * j + 1] = kx > key[2 * j + 1] ? kx : key[2 * j + 1];
+            }
+        }
+    }
+    if (has_next) {
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const unsigned long long ov = __shfl_down(key[i], off, kWave);
+                key[i] = ov > key[i] ? ov : key[i];
+            }
+        }
+        const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x >> 6;
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) lds[wid * 6 + i] = key[i];
+        }
+        __syncthreads();
+        if (threadIdx.x < 6) {
+            unsigned long long m = lds[threadIdx.x];
+            for (int w = 1; w < kIdtBlock / kWave; ++w) {
+                const unsigned long long ov = lds[w * 6 + threadIdx.x];
+                m = ov > m ? ov : m;
+            }
+            const int j = threadIdx.x >> 1, mmx = threadIdx.x & 1;
+            atomicMax(mm + (((size_t)b * n_iter + it + 1) * 3 + j) * 4 + mmx, m);   // target slots 0,1
+        }
+    }
+}
+
+static int idt_grid(int64_t n, int batch) {
+    int64_t want = (n + kIdtBlock - 1) / kIdtBlock;
+    int64_t cap = kTargetBlocks / (batch > 0 ? batch : 1);
+    if (cap < 8) cap = 8;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+template <typename T>
+static int idt_impl(const T *target, int64_t n_t, const T *reference, int64_t n_r, int batch, const double *rot,
+                    const double *rinv, int n_iter, int bins, int round_dr_f32, double *out, void *ws, size_t ws_bytes,
+                    const ct_idt_debug *dbg, void *stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    if (n_t < 0 || n_r < 0 || batch < 0 || n_iter < 0 || bins < 1 || bins > kIdtMaxBins) return CT_E_BADARG;
+    if (batch == 0) return CT_OK;
+    if ((n_t > 0 && (!target || !out)) || (n_r > 0 && !reference) || (n_iter > 0 && (!rot || !rinv))) return CT_E_BADARG;
+    if (!ws || (reinterpret_cast<uintptr_t>(ws) & 15)) return CT_E_WORKSPACE;
+    const IdtLayout l = idt_layout(ws, batch, n_iter > 0 ? n_iter : 1, bins);
+    if (ws_bytes < l.total_bytes) return CT_E_WORKSPACE;
+    hipError_t e;
+    if (n_iter == 0) return CT_E_BADARG;   // the host returns the input untouched in that case
+    if (n_t == 0) return CT_OK;
+    if ((e = hipMemsetAsync(ws, 0, l.zero_bytes, s)) != hipSuccess) return (int)e;
+    const int gt = idt_grid(n_t, batch), gr = idt_grid(n_r, batch);
+    // reference: lo/hi of every iteration's projection in one go; target: iteration 0 only
+    if (n_r > 0) {
+        hipLaunchKernelGGL((idt_minmax_kernel<T, 8>), dim3(gr, batch), dim3(kIdtBlock), 0, s, reference, n_r, rot, n_iter, 0,
+                           n_iter, 1, l.mm);
+        CT_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL((idt_minmax_kernel<T, 8>), dim3(gt, batch), dim3(kIdtBlock), 0, s, target, n_t, rot, n_iter, 0, 1, 0,
+                       l.mm);
+    CT_CHECK_LAUNCH();
+    const int gh = idt_grid(n_t > n_r ? n_t : n_r, batch);
+    for (int it = 0; it < n_iter; ++it) {
+        hipLaunchKernelGGL(idt_params_kernel, dim3(batch), dim3(64), 0, s, l.mm, l.par, n_iter, it, bins);
+        CT_CHECK_LAUNCH();
+        unsigned short *bi = (dbg && dbg->binidx) ? dbg->binidx : nullptr;
+        if (it == 0) {
+            hipLaunchKernelGGL((idt_hist_kernel<T, T>), dim3(gh, batch), dim3(kIdtBlock), 6 * bins * sizeof(unsigned int), s,
+                               target, n_t, reference, n_r, rot, l.par, n_iter, it, bins, l.hist, bi);
+        } else {
+            hipLaunchKernelGGL((idt_hist_kernel<double, T>), dim3(gh, batch), dim3(kIdtBlock),
+                               6 * bins * sizeof(unsigned int), s, (const double *)out, n_t, reference, n_r, rot, l.par,
+                               n_iter, it, bins, l.hist, bi);
+        }
+        CT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(idt_lut_kernel, dim3(3, batch), dim3(kIdtBlock), 3 * bins * sizeof(double), s, l.hist, l.par,
+                           n_iter, it, bins, l.lut);
+        CT_CHECK_LAUNCH();
+        const int rf = (round_dr_f32 && it == 0) ? 1 : 0;
+        if (it == 0) {
+            hipLaunchKernelGGL((idt_apply_kernel<T>), dim3(gt, batch), dim3(kIdtBlock), 3 * bins * sizeof(double2), s, target,
+                               out, n_t, rot, rinv, l.par, l.lut, n_iter, it, bins, rf, l.mm);
+        } else {
+            hipLaunchKernelGGL((idt_apply_kernel<double>), dim3(gt, batch), dim3(kIdtBlock), 3 * bins * sizeof(double2), s,
+                               (const double *)out, out, n_t, rot, rinv, l.par, l.lut, n_iter, it, bins, rf, l.mm);
+        }
+        CT_CHECK_LAUNCH();
+    }
+    if (dbg) {   // parity probes: device-to-device copies of the integer / LUT state
+        if (dbg->hist &&
+            (e = hipMemcpyAsync(dbg->hist, l.hist, (size_t)batch * n_iter * 6 * bins * sizeof(unsigned int),
+                                hipMemcpyDeviceToDevice, s)) != hipSuccess)
+            return (int)e;
+        if (dbg->lut && (e = hipMemcpyAsync(dbg->lut, l.lut, (size_t)batch * n_iter * 3 * bins * 2 * sizeof(double),
+                                            hipMemcpyDeviceToDevice, s)) != hipSuccess)
+            return (int)e;
+        if (dbg->par && (e = hipMemcpyAsync(dbg->par, l.par, (size_t)batch * n_iter * 3 * 4 * sizeof(double),
+                                            hipMemcpyDeviceToDevice, s)) != hipSuccess)
+            return (int)e;
+    }
+    return CT_OK;
+}
+
+}  // namespace ct
+
+extern "C" {
+
+size_t ct_idt_workspace_bytes(int batch, int n_iter, int bins) {
+    if (batch < 0 || n_iter < 0 || bins < 1 || bins > ct::kIdtMaxBins) return 0;
+    return ct::idt_layout(nullptr, batch, n_iter > 0 ? n_iter : 1, bins).total_bytes;
+}
+
+int ct_idt_f32(const float *target, int64_t n_t, const float *reference, int64_t n_r, int batch, const double *rot,
+               const double *rinv, int n_iter, int bins, int round_dr_f32, double *out, void *ws, size_t ws_bytes,
+               const ct_idt_debug *dbg, void *stream) {
+    return ct::idt_impl<float>(target, n_t, reference, n_r, batch, rot, rinv, n_iter, bins, round_dr_f32, out, ws, ws_bytes,
+                               dbg, stream);
+}
+
+int ct_idt_f64(const double *target, int64_t n_t, const double *reference, int64_t n_r, int batch, const double *rot,
+               const double *rinv, int n_iter, int bins, int round_dr_f32, double *out, void *ws, size_t ws_bytes,
+               const ct_idt_debug *dbg, void *stream) {
+    return ct::idt_impl<double>(target, n_t, reference, n_r, batch, rot, rinv, n_iter, bins, round_dr_f32, out, ws, ws_bytes,
+                                dbg, stream);
+}
+
+}  // extern "C"

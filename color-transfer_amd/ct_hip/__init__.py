@@ -43,7 +43,17 @@ SIGNATURES = {
     "ct_affine3x3_f32_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_p]),
     "ct_affine3x3_f64_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_p]),
     "ct_affine3x3_f32_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_p]),
+    "ct_idt_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
+    "ct_idt_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_sz,
+                            _c_p, _c_p]),
+    "ct_idt_f64": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_sz,
+                            _c_p, _c_p]),
 }
+
+
+class IdtDebug(ctypes.Structure):
+    """struct ct_idt_debug (include/ct_hip.h)"""
+    _fields_ = [("hist", _c_p), ("lut", _c_p), ("par", _c_p), ("binidx", _c_p)]
 
 _lib = None
 _lock = threading.Lock()
@@ -96,9 +106,10 @@ def _require_cuda(*tensors):
 _ws_cache = {}
 
 
-def workspace(kind, n_pixels, n_images, device):
+def workspace(kind, n_pixels, n_images, device, need=None):
     """Per-(device, stream) scratch buffer, grown on demand (never shrinks)."""
-    need = lib().ct_workspace_bytes(kind, n_pixels, n_images)
+    if need is None:
+        need = lib().ct_workspace_bytes(kind, n_pixels, n_images)
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < need:
@@ -203,3 +214,46 @@ def affine3x3(img, coef, out_dtype=torch.float64, out=None):
         raise CtHipError("no kernel for %s" % name)
     check(getattr(lib(), name)(_ptr(x), _ptr(coef), _ptr(out), n, B, _stream()))
     return out.view(img.shape)
+
+
+def idt(target, reference, rotations, bins=255, round_dr_f32=None, out=None, debug=False):
+    """methods.iterative.iterative_distribution_transfer on device tensors (methods/iterative.py:8-59).
+
+    target [H,W,3] or [B,H,W,3], reference likewise (its H x W may differ), float32 or float64 (same
+    dtype); rotations: float64 numpy/tensor [n_iter,3,3] (shared by the batch) or [B,n_iter,3,3].
+    Returns the float64 result (and a dict of device probe tensors when debug=True)."""
+    import numpy as np
+    x, _ = _as_batch(target)
+    r, _ = _as_batch(reference)
+    _require_cuda(x, r)
+    if x.dtype != r.dtype or x.shape[0] != r.shape[0]:
+        raise CtHipError("idt needs target/reference of one dtype and batch size")
+    B, n_t, n_r = x.shape[0], x.shape[1] * x.shape[2], r.shape[1] * r.shape[2]
+    rot = np.asarray(rotations.cpu().numpy() if isinstance(rotations, torch.Tensor) else rotations, dtype=np.float64)
+    if rot.ndim == 3:
+        rot = np.broadcast_to(rot, (B,) + rot.shape)
+    n_iter = rot.shape[1]
+    rinv = np.linalg.inv(rot)                       # host 3x3 inverses (the reference LU-solves, iterative.py:55)
+    both = torch.from_numpy(np.ascontiguousarray(np.stack([rot, rinv]).reshape(2, B, n_iter, 9))).to(x.device)
+    if round_dr_f32 is None:
+        round_dr_f32 = x.dtype == torch.float32
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float64, device=x.device)
+    need = lib().ct_idt_workspace_bytes(B, n_iter, bins)
+    if need == 0:
+        raise CtHipError("idt: unsupported bins=%d / n_iter=%d" % (bins, n_iter))
+    ws = workspace(CT_WS_IDT, 0, B, x.device, need=need)
+    dbg_t, dbg_p = {}, ctypes.c_void_p(0)
+    if debug:
+        dbg_t = {"hist": torch.zeros((B, n_iter, 2, 3, bins), dtype=torch.int32, device=x.device),
+                 "lut": torch.zeros((B, n_iter, 3, bins, 2), dtype=torch.float64, device=x.device),
+                 "par": torch.zeros((B, n_iter, 3, 4), dtype=torch.float64, device=x.device),
+                 "binidx": torch.zeros((B, n_iter, 3, n_t), dtype=torch.int16, device=x.device)}
+        st = IdtDebug(dbg_t["hist"].data_ptr(), dbg_t["lut"].data_ptr(), dbg_t["par"].data_ptr(),
+                      dbg_t["binidx"].data_ptr())
+        dbg_p = ctypes.cast(ctypes.pointer(st), ctypes.c_void_p)
+    fn = getattr(lib(), "ct_idt_" + _suffix(x))
+    check(fn(_ptr(x), n_t, _ptr(r), n_r, B, _ptr(both[0]), _ptr(both[1]), n_iter, bins, int(bool(round_dr_f32)),
+             _ptr(out), _ptr(ws), ws.numel(), dbg_p, _stream()))
+    out = out.view(target.shape)
+    return (out, dbg_t) if debug else out

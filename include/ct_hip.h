@@ -101,6 +101,34 @@ int ct_affine3x3_f64_f64(const double *in, const double *coef, double *out, int6
 int ct_affine3x3_f32_f32(const float *in, const double *coef, float *out, int64_t n_pixels,
                          int batch, void *stream);
 
+/* ---- a4: methods.iterative.iterative_distribution_transfer (methods/iterative.py:8-59) ----
+ * Per iteration: projection on the rotated axes (float64, fma chain), exact lo/hi, 2x3 histograms
+ * with numpy's bin rule (LDS-binned integer atomics), cumulative LUT, np.interp apply with the
+ * `left=0` quirk, back-rotation.  The rotation matrices are DATA drawn by the caller (the
+ * reference draws them from numpy's global RNG, iterative.py:32):
+ *   rot, rinv : device [batch][n_iter][9] float64 row-major, rinv = inverse(rot)
+ *   out       : device [batch][n_t][3] float64 (the reference returns float64); also the working image
+ *   round_dr_f32 : 1 reproduces `d_r = np.empty_like(target.T)` being float32 on iteration 0 for
+ *                  float32 callers (iterative.py:36)
+ *   bins <= 1024, n_iter >= 1;  ws: ct_idt_workspace_bytes(batch, n_iter, bins) bytes
+ *   dbg  : NULL, or device buffers receiving the integer/LUT state (parity probes):
+ *          hist [batch][n_iter][2][3][bins] u32 (0 = target, 1 = reference), lut [batch][n_iter][3][bins][2]
+ *          (f, slope), par [batch][n_iter][3][4] (lo, hi, step, bins/(hi-lo)), binidx [batch][n_iter][3][n_t] u16 */
+typedef struct ct_idt_debug {
+    unsigned int *hist;
+    double *lut;
+    double *par;
+    unsigned short *binidx;
+} ct_idt_debug;
+
+size_t ct_idt_workspace_bytes(int batch, int n_iter, int bins);
+int ct_idt_f32(const float *target, int64_t n_t, const float *reference, int64_t n_r, int batch,
+               const double *rot, const double *rinv, int n_iter, int bins, int round_dr_f32,
+               double *out, void *ws, size_t ws_bytes, const ct_idt_debug *dbg, void *stream);
+int ct_idt_f64(const double *target, int64_t n_t, const double *reference, int64_t n_r, int batch,
+               const double *rot, const double *rinv, int n_iter, int bins, int round_dr_f32,
+               double *out, void *ws, size_t ws_bytes, const ct_idt_debug *dbg, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
