@@ -257,3 +257,84 @@ def idt(target, reference, rotations, bins=255, round_dr_f32=None, out=None, deb
              _ptr(out), _ptr(ws), ws.numel(), dbg_p, _stream()))
     out = out.view(target.shape)
     return (out, dbg_t) if debug else out
+
+
+# ------------------------------------------------------------------------------------------------
+# DCMCS3DI building blocks (csrc/cnn.hip)
+# ------------------------------------------------------------------------------------------------
+_c_ll = ctypes.c_longlong
+SIGNATURES.update({
+    "ct_conv2d_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ll, _c_ll,
+                               _c_ll, _c_int, _c_int, _c_p]),
+    "ct_pam_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
+    "ct_pam_attend_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    "ct_pam_valid_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_sz, _c_p]),
+})
+
+
+def pack_conv_weight(weight, bias):
+    """torch Conv2d parameters -> the MFMA A-operand layout of ct_conv2d_f32 (include/ct_hip.h):
+    wp[tap][cin_pair][2][32*ceil(cout/32)], bias zero padded."""
+    cout, cin, kh, kw = weight.shape
+    assert kh == kw and kh in (1, 3)
+    coutp = 32 * ((cout + 31) // 32)
+    cinp = 2 * ((cin + 1) // 2)
+    w = torch.zeros((coutp, cinp, kh, kw), dtype=torch.float32, device=weight.device)
+    w[:cout, :cin] = weight.detach().float()
+    wp = w.permute(2, 3, 1, 0).reshape(kh * kw, cinp // 2, 2, coutp).contiguous()
+    b = torch.zeros(coutp, dtype=torch.float32, device=weight.device)
+    if bias is not None:
+        b[:cout] = bias.detach().float()
+    return wp, b
+
+
+def _nchw_bstride(t):
+    n, c, h, w = t.shape
+    if t.stride(3) != 1 or t.stride(2) != w or t.stride(1) != h * w:
+        raise CtHipError("conv2d needs NCHW tensors with dense planes (channel slices are fine)")
+    return t.stride(0)
+
+
+def conv2d(x, wp, bias, cout, ksize, act=0, residual=None, clamp=False, out=None):
+    """Conv2d(ksize, padding=ksize//2) + bias [+ LeakyReLU(0.01)] [+ residual] [clamp 0..1], float32 NCHW."""
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise CtHipError("conv2d needs float32 CUDA tensors (no CPU path)")
+    n, cin, h, w = x.shape
+    if out is None:
+        out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+    rs = _nchw_bstride(residual) if residual is not None else 0
+    check(lib().ct_conv2d_f32(_ptr(x), _ptr(wp), _ptr(bias), _ptr(residual) if residual is not None else _c_p(0),
+                              _ptr(out), n, cin, cout, h, w, ksize, _nchw_bstride(x), _nchw_bstride(out), rs, int(act),
+                              int(bool(clamp)), _stream()))
+    return out
+
+
+def pam_attend(q, k, v, rgb, want_att=False):
+    """softmax(q.k/c) @ [v | rgb] per image row (pasmnet/attention.py:39-41, utils.py:30,123-125)."""
+    for t in (q, k, v, rgb):
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+            raise CtHipError("pam_attend needs contiguous float32 CUDA tensors")
+    n, c, h, w = q.shape
+    cv = v.shape[1]
+    out_v = torch.empty_like(v)
+    out_rgb = torch.empty_like(rgb)
+    att = torch.empty((n, h, w, w), dtype=torch.float32, device=q.device) if want_att else None
+    check(lib().ct_pam_attend_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(rgb), _ptr(out_v), _ptr(out_rgb),
+                                  _ptr(att) if att is not None else _c_p(0), n, c, cv, h, w, _stream()))
+    return out_v, out_rgb, att
+
+
+def pam_valid(q, k, want_att=False):
+    """valid mask (as 0/1 float [n,1,h,w]) + pre-threshold column sums of softmax(q.k/c) (utils.py:31,34-35)."""
+    for t in (q, k):
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+            raise CtHipError("pam_valid needs contiguous float32 CUDA tensors")
+    n, c, h, w = q.shape
+    valid = torch.empty((n, 1, h, w), dtype=torch.float32, device=q.device)
+    colsum = torch.empty((n, 1, h, w), dtype=torch.float32, device=q.device)
+    att = torch.empty((n, h, w, w), dtype=torch.float32, device=q.device) if want_att else None
+    need = lib().ct_pam_workspace_bytes(n, h, w)
+    ws = workspace(-1, 0, 0, q.device, need=need)
+    check(lib().ct_pam_valid_f32(_ptr(q), _ptr(k), _ptr(valid), _ptr(colsum), _ptr(att) if att is not None else _c_p(0),
+                                 n, c, h, w, _ptr(ws), ws.numel(), _stream()))
+    return valid, colsum, att

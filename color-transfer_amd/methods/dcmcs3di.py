@@ -1,0 +1,125 @@
+"""Deep Color Mismatch Correction in Stereoscopic 3D Images (Croci et al. 2021) -- MI355X drop-in
+for the FORWARD pass of the reference's methods/dcmcs3di.py:29-66.
+
+Same constructor arguments, parameter names/shapes (reference checkpoints `load_state_dict`
+strictly) and `forward(left, right, inference)` return structure.  Every convolution runs in
+ct_conv2d_f32 (LDS-tiled implicit GEMM on exact-f32 MFMA), the parallax attention in
+ct_pam_attend_f32 / ct_pam_valid_f32; torch only allocates tensors and concatenates.  Training
+(`step`, losses, logging: dcmcs3di.py:68-147) is out of scope.  No CPU fallback.
+"""
+import torch
+
+import ct_hip
+from pasmnet.attention import PAB
+from pasmnet.backbone import ResB
+
+
+class _Packed:
+    """Packed (MFMA operand layout) copies of a module's conv weights, rebuilt when parameters change."""
+
+    def __init__(self):
+        self.cache = {}
+
+    def get(self, conv):
+        key = id(conv)
+        ver = (conv.weight._version, conv.weight.data_ptr(), conv.bias._version if conv.bias is not None else -1,
+               str(conv.weight.device))
+        hit = self.cache.get(key)
+        if hit is None or hit[0] != ver:
+            hit = (ver, ct_hip.pack_conv_weight(conv.weight, conv.bias))
+            self.cache[key] = hit
+        return hit[1]
+
+
+_packed = _Packed()
+
+
+def conv_forward(conv, x, act=0, residual=None, clamp=False, out=None):
+    wp, b = _packed.get(conv)
+    return ct_hip.conv2d(x, wp, b, conv.out_channels, conv.kernel_size[0], act=act, residual=residual, clamp=clamp,
+                         out=out)
+
+
+def resb_forward(resb, x, out=None):
+    """x + conv(LeakyReLU(conv(x)))  (pasmnet/backbone.py:14-15)"""
+    t = conv_forward(resb.body[0], x, act=1)
+    return conv_forward(resb.body[2], t, residual=x, out=out)
+
+
+def sequential_forward(seq, x):
+    for m in seq:
+        if isinstance(m, ResB):
+            x = resb_forward(m, x)
+        elif isinstance(m, torch.nn.Conv2d):
+            x = conv_forward(m, x)
+        else:
+            raise TypeError("unexpected module %r" % (m,))
+    return x
+
+
+class DCMCS3DI(torch.nn.Module):
+    def __init__(self, extraction_layers=18, transfer_layers=6, channels=64):
+        super().__init__()
+        self.hparams = type("HParams", (), dict(extraction_layers=extraction_layers, transfer_layers=transfer_layers,
+                                                channels=channels))()
+        if channels != 64:
+            raise ValueError("the HIP kernels are built for channels=64 (the reference's configs/dcmcs3di.yaml)")
+        # construction order == reference (dcmcs3di.py:41-51): torch.manual_seed(s) gives the same init
+        self.extraction = torch.nn.Sequential(torch.nn.Conv2d(3, channels, kernel_size=3, padding=1))
+        for _ in range(extraction_layers):
+            self.extraction.append(ResB(channels, channels))
+        self.matcher = PAB(channels)
+        self.transfer = torch.nn.Sequential(torch.nn.Conv2d(2 * channels + 1, channels, kernel_size=1))
+        for _ in range(transfer_layers):
+            self.transfer.append(ResB(channels, channels))
+        self.transfer.append(torch.nn.Conv2d(channels, channels // 2, kernel_size=3, padding=1))
+        self.transfer.append(torch.nn.Conv2d(channels // 2, 3, kernel_size=3, padding=1))
+
+    @torch.no_grad()
+    def forward_parts(self, left, right, want_att=False, want_valid_right=False):
+        """The forward pass with its intermediates (used by forward() and by the parity tests)."""
+        if not left.is_cuda:
+            raise ct_hip.CtHipError("DCMCS3DI runs on the GPU only (no CPU fallback)")
+        left = left.contiguous().float()
+        right = right.contiguous().float()
+        B = left.shape[0]
+        both = torch.cat([left, right], dim=0)
+        fea = sequential_forward(self.extraction, both)                    # dcmcs3di.py:54-55
+        head = resb_forward(self.matcher.head, fea)                        # attention.py:35-36
+        q = conv_forward(self.matcher.query, head)                         # attention.py:39,44
+        k = conv_forward(self.matcher.key, head)                           # attention.py:40,45
+        fea_left, fea_right = fea[:B], fea[B:]
+        v = conv_forward(self.matcher.value, fea_right)                    # dcmcs3di.py:58
+        # right-to-left: Q(left) . K(right)
+        fea_warped, warped_rgb, att_r2l = ct_hip.pam_attend(q[:B], k[B:], v, right, want_att=want_att)
+        # left-to-right softmax, column sums -> valid mask of the LEFT view (utils.py:31,34-35)
+        valid_left, colsum_left, att_l2r = ct_hip.pam_valid(q[B:], k[:B], want_att=want_att)
+        x = torch.cat([fea_left, fea_warped, valid_left], dim=1)           # dcmcs3di.py:59 (bool -> float)
+        n_t = len(self.transfer)
+        for i in range(n_t - 1):
+            m = self.transfer[i]
+            x = resb_forward(m, x) if isinstance(m, ResB) else conv_forward(m, x)
+        pre_clamp = conv_forward(self.transfer[n_t - 1], x)
+        parts = dict(fea_left=fea_left, fea_right=fea_right, fea_warped=fea_warped, warped_rgb=warped_rgb,
+                     att_r2l=att_r2l, att_l2r=att_l2r, valid_left=valid_left, colsum_left=colsum_left,
+                     pre_clamp=pre_clamp, corrected=pre_clamp.clamp(min=0, max=1))
+        if want_valid_right:
+            parts["valid_right"], parts["colsum_right"], _ = ct_hip.pam_valid(q[:B], k[B:])
+        return parts
+
+    def forward(self, left, right, inference=False, return_attention=None):
+        """Same return structure as the reference (dcmcs3di.py:61-66):
+        (corrected, ((att_r2l, att_l2r), (cycle_l, cycle_r), (valid_left, valid_right), warp(right, att_r2l))).
+        The [B,H,W,W] attention maps (15.9 GB each at 1080p) are materialised only when
+        `return_attention` is true (default: only in training mode, inference=False)."""
+        want_att = (not inference) if return_attention is None else bool(return_attention)
+        p = self.forward_parts(left, right, want_att=want_att, want_valid_right=not inference)
+        valid_left = p["valid_left"] > 0.5
+        if inference:
+            att_cycle = (None, None)
+            valid = (valid_left, None)
+        else:
+            att_cycle = (torch.matmul(p["att_r2l"], p["att_l2r"]), torch.matmul(p["att_l2r"], p["att_r2l"])) \
+                if want_att else (None, None)
+            valid = (valid_left, p["valid_right"] > 0.5)
+        return p["corrected"], ((p["att_r2l"], p["att_l2r"]), att_cycle, valid, p["warped_rgb"])

@@ -129,6 +129,35 @@ int ct_idt_f64(const double *target, int64_t n_t, const double *reference, int64
                const double *rot, const double *rinv, int n_iter, int bins, int round_dr_f32,
                double *out, void *ws, size_t ws_bytes, const ct_idt_debug *dbg, void *stream);
 
+/* ---- a5-a9: DCMCS3DI forward building blocks (methods/dcmcs3di.py:41-66, pasmnet/ *.py) ----
+ * NCHW float32 tensors as the reference's modules exchange them; exact-f32 MFMA arithmetic.
+ *
+ * ct_conv2d_f32: torch.nn.Conv2d(cin, cout, ksize, padding=ksize/2) + bias, then optionally
+ *   LeakyReLU(0.01) (act=1; pasmnet/backbone.py:10), `+ residual` (ResB skip, backbone.py:15),
+ *   clamp to [0,1] (dcmcs3di.py:61).  ksize in {1,3}, cout <= 64.
+ *   wp   : weights packed [ksize*ksize][ceil(cin/2)][2][32*ceil(cout/32)] (zero padded):
+ *          wp[ky*ksize+kx][ci/2][ci%2][co] = weight[co][ci][ky][kx]
+ *   bias : [32*ceil(cout/32)] zero padded
+ *   *_bstride : elements between consecutive images of the batch (lets in/out be channel slices)   */
+int ct_conv2d_f32(const float *in, const float *wp, const float *bias, const float *residual,
+                  float *out, int n, int cin, int cout, int h, int w, int ksize,
+                  long long in_bstride, long long out_bstride, long long res_bstride, int act,
+                  int clamp, void *stream);
+
+/* Parallax attention, one direction (pasmnet/attention.py:39-41, utils.py:30, utils.py:123-125):
+ *   P = softmax_j( sum_c q[c][h][i] k[c][h][j] / c ) ;  out_v[c][h][i] = sum_j P[i][j] v[c][h][j],
+ *   out_rgb likewise for the 3 channels of `rgb` (dcmcs3di.py:58,65).  att: NULL, or [n][h][w][w]
+ *   receiving P (the API's att_right2left).  w <= ~1000 (one 32-query tile of S lives in LDS).    */
+int ct_pam_attend_f32(const float *q, const float *k, const float *v, const float *rgb,
+                      float *out_v, float *out_rgb, float *att, int n, int c, int cv, int h, int w,
+                      void *stream);
+/* valid mask of the opposite direction (utils.py:31,34-35): valid[n][0][h][j] = 1.0 if
+ * sum_i softmax_j(q.k/c)[i][j] > 0.1 else 0.0; colsum (nullable) receives the sums themselves.
+ * ws: ct_pam_workspace_bytes(n,h,w).  Column sums are added in a fixed order (deterministic).   */
+size_t ct_pam_workspace_bytes(int n, int h, int w);
+int ct_pam_valid_f32(const float *q, const float *k, float *valid, float *colsum, float *att,
+                     int n, int c, int h, int w, void *ws, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
