@@ -23,14 +23,17 @@ namespace ct {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kConvTH = 4;      // output rows per workgroup (one per wave)
+constexpr int kConvTH = 8;      // output rows per workgroup (two per wave)
 constexpr int kConvTW = 32;     // output columns per workgroup (= MFMA N)
-constexpr int kConvChunk = 64;  // input channels staged in LDS at a time
+constexpr int kConvChunk = 32;  // input channels staged in LDS at a time (one pipeline stage)
+constexpr int kNumCUs = 256;    // MI355X
 
 // ---------------------------------------------------------------------------------------------
 // conv_mfma_kernel: out[n][co][y][x] = epilogue( bias[co] + sum_{ci,ky,kx} w[co][ci][ky][kx] in[n][ci][y+ky-p][x+kx-p] )
 //   wp   : weights packed as [tap][cin_pair][2][MT*32]  (zero padded in cin and cout)
-//   grid : (ceil(W/32), ceil(H/4), N) ; block 256 ; dynamic LDS = tile + one tap of weights
+//   grid : persistent, two workgroups per CU walking the (n, y/8, x/32) tiles; block 256;
+//          dynamic LDS = halo tile + 2 weight slices (double buffer); the NEXT tile's halo is prefetched into
+//          registers (43 VGPRs) while the current one is multiplied, so HBM/L2 latency hides under the MFMAs
 // ---------------------------------------------------------------------------------------------
 struct ConvArgs {
     const float *in;
@@ -45,58 +48,122 @@ struct ConvArgs {
 };
 
 template <int KS, int MT>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles_x, int tiles_y, int n_tiles) {
     constexpr int PAD = KS / 2;
     constexpr int ROWS = kConvTH + KS - 1;
     constexpr int TWP = kConvTW + KS - 1;
-    constexpr int CS = ROWS * TWP;            // floats per channel in the LDS tile
+    constexpr int CS = ROWS * TWP;             // floats per channel in the LDS tile
+    constexpr int ELEMS = kConvChunk * CS;     // floats of one staged (tile, channel chunk)
+    constexpr int PF = (ELEMS + 255) / 256;    // prefetch registers per thread (85 for 3x3, 64 for 1x1)
     constexpr int COUTP = MT * 32;
+    constexpr int RPW = kConvTH / 4;           // output rows per wave
+    constexpr int TAPS = KS * KS;
+    constexpr int WSLICE = (kConvChunk / 2) * 2 * COUTP;   // floats of one (tap, chunk) weight slice
+    constexpr int WV4 = WSLICE / 4 / 256;      // float4 per thread per slice
     extern __shared__ float smem[];
     float *tin = smem;                         // [kConvChunk][ROWS][TWP]
-    float *tw = smem + kConvChunk * CS;        // [kConvChunk/2][2][COUTP]
+    float *tw0 = smem + ELEMS;                 // 2 x [kConvChunk/2][2][COUTP]  (double buffer)
 
-    const int x0 = blockIdx.x * kConvTW, y0 = blockIdx.y * kConvTH, n = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, hl = lane >> 5;
-    const float *in = a.in + (size_t)n * a.in_bstride;
     const size_t plane = (size_t)a.H * a.W;
-
-    f32x16 acc[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-
     const int cin_pairs_total = (a.cin + 1) >> 1;
-    for (int c0 = 0; c0 < a.cin; c0 += kConvChunk) {
+    const int n_chunks = (a.cin + kConvChunk - 1) / kConvChunk;
+    const int my_tiles = (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int n_stages = my_tiles * n_chunks;  // a stage = (tile, channel chunk)
+
+    // ---- (tile, chunk) halo tile -> registers; the loads stay in flight while the previous stage computes ----
+    // Offsets are 32-bit relative to the (image, chunk) base: a chunk spans < 2^31 elements.
+    float pf[PF];
+    const unsigned int uplane = (unsigned int)plane;
+    auto fetch_tile = [&](int stage) {
+        const int k = stage / n_chunks, chunk = stage - k * n_chunks;
+        const int t = blockIdx.x + k * gridDim.x;
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
+        const int x0 = tx * kConvTW, y0 = ty * kConvTH, c0 = chunk * kConvChunk;
         const int cc = (a.cin - c0) < kConvChunk ? (a.cin - c0) : kConvChunk;
-        const int ccp = (cc + 1) >> 1;
-        __syncthreads();   // everyone is done with the previous chunk's tile
-        // ---- stage the input halo tile (zero padding outside the image / beyond cin) ----
-        for (int idx = tid; idx < 2 * ccp * CS; idx += 256) {
-            const int c = idx / CS, rem = idx - c * CS;
-            const int yy = rem / TWP, xx = rem - yy * TWP;
-            const int gy = y0 + yy - PAD, gx = x0 + xx - PAD;
-            float v = 0.f;
-            if (c < cc && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = in[(size_t)(c0 + c) * plane + (size_t)gy * a.W + gx];
-            tin[idx] = v;
-        }
-        for (int tap = 0; tap < KS * KS; ++tap) {
-            __syncthreads();   // tile staged (first tap) / previous tap's weights consumed
-            {   // ---- stage this (tap, chunk) slice of the packed weights: contiguous ccp*2*COUTP floats ----
-                const float4 *src = reinterpret_cast<const float4 *>(a.wp + ((size_t)tap * cin_pairs_total + (c0 >> 1)) * 2 * COUTP);
-                float4 *dst = reinterpret_cast<float4 *>(tw);
-                for (int i = tid; i < ccp * 2 * COUTP / 4; i += 256) dst[i] = src[i];
-            }
-            __syncthreads();
-            const int ky = tap / KS, kx = tap - ky * KS;
-            const float *brow = tin + hl * CS + (wave + ky) * TWP + kx + nl;
-            const float *arow = tw + hl * COUTP + nl;
-            auto kstep = [&](int p) {
-                const float b = brow[p * 2 * CS];
+        const float *in = a.in + (size_t)n * a.in_bstride + (size_t)c0 * plane;
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const float w = arow[p * 2 * COUTP + m * 32];
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b, acc[m], 0, 0, 0);
+        for (int i = 0; i < PF; ++i) {
+            {
+                int e = tid + i * 256;
+                // opaque to the optimiser: otherwise LICM hoists all PF index decompositions (c, yy, xx are
+                // stage-invariant) out of the stage loop and keeps 3*PF values alive -> hundreds of spills
+                asm volatile("" : "+v"(e));
+                const int c = e / CS, rem = e - c * CS;
+                const int yy = rem / TWP, xx = rem - yy * TWP;
+                const int gy = y0 + yy - PAD, gx = x0 + xx - PAD;
+                const bool ok = (e < ELEMS) && (c < cc) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                // exec-masked load into a pre-zeroed register: no predicate has to outlive the load
+                float v = 0.f;
+                if (ok) v = in[(unsigned int)c * uplane + (unsigned int)(gy * a.W + gx)];
+                pf[i] = v;
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int e = tid + i * 256;
+            if (e < ELEMS) tin[e] = pf[i];
+        }
+    };
+    // ---- weight slice (tap, chunk) -> registers (zero beyond the chunk's channel pairs) ----
+    float4 wreg[WV4];
+    auto fetch_w = [&](int chunk, int tap) {
+        const int c0 = chunk * kConvChunk;
+        const int cc = (a.cin - c0) < kConvChunk ? (a.cin - c0) : kConvChunk;
+        const int nv = ((cc + 1) >> 1) * 2 * COUTP / 4;
+        const float4 *src = reinterpret_cast<const float4 *>(a.wp + ((size_t)tap * cin_pairs_total + (c0 >> 1)) * 2 * COUTP);
+#pragma unroll
+        for (int i = 0; i < WV4; ++i) {
+            const int e = tid + i * 256;
+            wreg[i] = (e < nv) ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_w = [&](int buf) {
+        float4 *dst = reinterpret_cast<float4 *>(tw0 + buf * WSLICE);
+#pragma unroll
+        for (int i = 0; i < WV4; ++i) dst[tid + i * 256] = wreg[i];
+    };
+
+    if (n_stages == 0) return;
+    f32x16 acc[RPW][MT];
+    fetch_tile(0);
+    fetch_w(0, 0);
+    store_tile();
+    int wbuf = 0;
+    for (int stage = 0; stage < n_stages; ++stage) {
+        const int k = stage / n_chunks, chunk = stage - k * n_chunks;
+        const int cc = (a.cin - chunk * kConvChunk) < kConvChunk ? (a.cin - chunk * kConvChunk) : kConvChunk;
+        const int ccp = (cc + 1) >> 1;
+        if (chunk == 0) {
+#pragma unroll
+            for (int q = 0; q < RPW; ++q)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[q][m][r] = 0.f;
+        }
+        store_w(wbuf);
+        __syncthreads();                                   // this stage's tile and tap-0 weights are visible
+        const bool next_stage = (stage + 1 < n_stages);
+        if (next_stage) fetch_tile(stage + 1);            // the next halo tile: in flight under this stage's MFMAs
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const bool last_tap = (tap + 1 == TAPS);
+            if (!last_tap) fetch_w(chunk, tap + 1);
+            else if (next_stage) fetch_w((chunk + 1 == n_chunks) ? 0 : chunk + 1, 0);
+            const int ky = tap / KS, kx = tap - ky * KS;
+            const float *brow = tin + hl * CS + (wave * RPW + ky) * TWP + kx + nl;
+            const float *arow = tw0 + wbuf * WSLICE + hl * COUTP + nl;
+            auto kstep = [&](int p) {
+                float w[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) w[m] = arow[p * 2 * COUTP + m * 32];
+#pragma unroll
+                for (int q = 0; q < RPW; ++q) {
+                    const float b = brow[p * 2 * CS + q * TWP];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[m], b, acc[q][m], 0, 0, 0);
                 }
             };
             if (ccp == kConvChunk / 2) {   // the common full chunk: compile-time trip count, fully unrolled
@@ -105,34 +172,52 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
             } else {
                 for (int p = 0; p < ccp; ++p) kstep(p);
             }
+            wbuf ^= 1;
+            if (!last_tap) {
+                store_w(wbuf);             // the other buffer: nobody reads it during this tap
+                __syncthreads();
+            }
         }
-    }
-    // ---- epilogue: lane owns pixel (y0+wave, x0+nl) and channels (r&3)+8(r>>2)+4hl of each 32-tile ----
-    const int y = y0 + wave, x = x0 + nl;
-    if (y < a.H && x < a.W) {
-        float *out = a.out + (size_t)n * a.out_bstride + (size_t)y * a.W + x;
-        const float *res = a.residual ? a.residual + (size_t)n * a.res_bstride + (size_t)y * a.W + x : nullptr;
+        if (chunk + 1 == n_chunks) {
+            // ---- epilogue: lane owns pixels (y0 + wave*RPW + q, x0+nl), channels (r&3)+8(r>>2)+4hl of each 32-tile ----
+            const int t = blockIdx.x + k * gridDim.x;
+            const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
+            const int x = tx * kConvTW + nl;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
+            for (int q = 0; q < RPW; ++q) {
+                const int y = ty * kConvTH + wave * RPW + q;
+                if (y < a.H && x < a.W) {
+                    // 32-bit element offsets inside one image (cout * plane < 2^32): keeps the 64 stores cheap in registers
+                    float *out = a.out + (size_t)n * a.out_bstride;
+                    const float *res = a.residual ? a.residual + (size_t)n * a.res_bstride : nullptr;
+                    const unsigned int pix = (unsigned int)(y * a.W + x);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-                if (co < a.cout) {
-                    float v = acc[m][r] + a.bias[co];
-                    if (a.act == 1) v = v > 0.f ? v : 0.01f * v;
-                    if (res) v += res[(size_t)co * plane];
-                    if (a.clamp) v = fminf(fmaxf(v, 0.f), 1.f);
-                    out[(size_t)co * plane] = v;
+                    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+                            if (co < a.cout) {
+                                const unsigned int off = (unsigned int)co * uplane + pix;
+                                float v = acc[q][m][r] + a.bias[co];
+                                if (a.act == 1) v = v > 0.f ? v : 0.01f * v;
+                                if (res) v += res[off];
+                                if (a.clamp) v = fminf(fmaxf(v, 0.f), 1.f);
+                                out[off] = v;
+                            }
+                        }
+                    }
                 }
             }
         }
+        __syncthreads();                   // every wave is done reading this stage's tile
+        if (next_stage) store_tile();      // waits for the prefetched loads, then fills the tile
     }
 }
 
 template <int KS, int MT>
 static int launch_conv(const ConvArgs &a, int N, hipStream_t s) {
     constexpr int ROWS = kConvTH + KS - 1, TWP = kConvTW + KS - 1;
-    const size_t lds = (size_t)(kConvChunk * ROWS * TWP + (kConvChunk / 2) * 2 * MT * 32) * sizeof(float);
+    const size_t lds = (size_t)(kConvChunk * ROWS * TWP + 2 * (kConvChunk / 2) * 2 * MT * 32) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<KS, MT>),
@@ -140,8 +225,11 @@ static int launch_conv(const ConvArgs &a, int N, hipStream_t s) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    dim3 grid((a.W + kConvTW - 1) / kConvTW, (a.H + kConvTH - 1) / kConvTH, N);
-    hipLaunchKernelGGL((conv_mfma_kernel<KS, MT>), grid, dim3(256), lds, s, a);
+    const int tiles_x = (a.W + kConvTW - 1) / kConvTW, tiles_y = (a.H + kConvTH - 1) / kConvTH;
+    const long long n_tiles = (long long)tiles_x * tiles_y * N;
+    if (n_tiles > 0x7fffffffLL) return CT_E_BADARG;
+    const int grid = n_tiles < 2 * kNumCUs ? (int)n_tiles : 2 * kNumCUs;   // persistent: two workgroups per CU
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, MT>), dim3(grid), dim3(256), lds, s, a, tiles_x, tiles_y, (int)n_tiles);
     CT_CHECK_LAUNCH();
     return CT_OK;
 }
