@@ -45,6 +45,7 @@ struct ConvArgs {
     long long in_bstride, out_bstride, res_bstride;   // elements between images of a batch
     int act;     // 0 none, 1 LeakyReLU(0.01)
     int clamp;   // 1 = clamp to [0,1]
+    unsigned long long *prof;   // diagnostic builds only (CT_CONV_PROFILE); NULL otherwise
 };
 
 template <int KS, int MT>
@@ -58,11 +59,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
     constexpr int COUTP = MT * 32;
     constexpr int RPW = kConvTH / 4;           // output rows per wave
     constexpr int TAPS = KS * KS;
-    constexpr int WSLICE = (kConvChunk / 2) * 2 * COUTP;   // floats of one (tap, chunk) weight slice
-    constexpr int WV4 = WSLICE / 4 / 256;      // float4 per thread per slice
     extern __shared__ float smem[];
     float *tin = smem;                         // [kConvChunk][ROWS][TWP]
-    float *tw0 = smem + ELEMS;                 // 2 x [kConvChunk/2][2][COUTP]  (double buffer)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, hl = lane >> 5;
     const size_t plane = (size_t)a.H * a.W;
@@ -107,77 +105,142 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
             if (e < ELEMS) tin[e] = pf[i];
         }
     };
-    // ---- weight slice (tap, chunk) -> registers (zero beyond the chunk's channel pairs) ----
-    float4 wreg[WV4];
-    auto fetch_w = [&](int chunk, int tap) {
+    // ---- A operand: this lane's weights of one (tap, chunk) slice, straight from L1/L2 into registers ----
+    // (all waves of all workgroups read the same 147 KB: it lives in L2/L1; no LDS staging and therefore
+    //  no barrier per tap -- the waves of a workgroup only meet twice per stage)
+    constexpr int KSTEPS = kConvChunk / 2;
+    auto load_w = [&](int chunk, int tap, float (&w)[KSTEPS][MT]) {
         const int c0 = chunk * kConvChunk;
         const int cc = (a.cin - c0) < kConvChunk ? (a.cin - c0) : kConvChunk;
-        const int nv = ((cc + 1) >> 1) * 2 * COUTP / 4;
-        const float4 *src = reinterpret_cast<const float4 *>(a.wp + ((size_t)tap * cin_pairs_total + (c0 >> 1)) * 2 * COUTP);
+        const int ccp = (cc + 1) >> 1;
+        const float *src = a.wp + ((size_t)tap * cin_pairs_total + (c0 >> 1)) * 2 * COUTP + hl * COUTP + nl;
 #pragma unroll
-        for (int i = 0; i < WV4; ++i) {
-            const int e = tid + i * 256;
-            wreg[i] = (e < nv) ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto store_w = [&](int buf) {
-        float4 *dst = reinterpret_cast<float4 *>(tw0 + buf * WSLICE);
+        for (int p = 0; p < KSTEPS; ++p)
 #pragma unroll
-        for (int i = 0; i < WV4; ++i) dst[tid + i * 256] = wreg[i];
+            for (int m = 0; m < MT; ++m) w[p][m] = (p < ccp) ? src[p * 2 * COUTP + m * 32] : 0.f;
     };
 
     if (n_stages == 0) return;
+#ifdef CT_CONV_PROFILE
+    // diagnostic build: per-phase cycle totals of wave 0 of each workgroup -> a.prof[block][8]
+    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt0;
+#define CT_STAMP(var) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#define CT_PHASE(i) do { unsigned long long t__; CT_STAMP(t__); pt[i] += t__ - pt0; pt0 = t__; } while (0)
+    CT_STAMP(pt0);
+#else
+#define CT_PHASE(i) do { } while (0)
+#endif
     f32x16 acc[RPW][MT];
+    float wa[KSTEPS][MT], wb[KSTEPS][MT];
+    // ---- phase stagger --------------------------------------------------------------------------------------
+    // All workgroups start together and do identical work, so left alone they reach their epilogues (a burst
+    // of output stores + residual loads, no MFMA) at the same instant, chip-wide, and the matrix pipes idle.
+    // The workgroup in the odd hardware wave slot of its SIMD (= the second of the two co-resident ones)
+    // therefore waits for half a tile of its partner's work: from then on one of the two is always in its
+    // MFMA loop while the other drains/loads.  Pure scheduling: results do not depend on it.
+    if (my_tiles >= 2) {
+        const unsigned int hw_wave_slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | ((4 - 1) << 11));   // HW_ID[3:0]
+        if (hw_wave_slot & 1) {
+            const int half_tile_cycles = n_chunks * TAPS * KSTEPS * RPW * MT * 64 / 2;
+            for (int c = 0; c < half_tile_cycles; c += 64 * 64) __builtin_amdgcn_s_sleep(64);
+        }
+    }
+    // accumulator pre-load for tile k: residual (ResB skip, act == 0) or zero.  Issued right after the previous
+    // tile's stores, i.e. a whole barrier + tile-store phase before the first MFMA needs it.
+    const bool res_in_acc = (a.residual != nullptr) && (a.act == 0);
+    auto init_acc = [&](int k) {
+        const int t = blockIdx.x + k * gridDim.x;
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
+        const int x = tx * kConvTW + nl;
+        const float *__restrict__ res = res_in_acc ? a.residual + (size_t)n * a.res_bstride : nullptr;
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            const int y = ty * kConvTH + wave * RPW + q;
+            const bool inb = res_in_acc && (y < a.H) && (x < a.W);
+            const unsigned int pix = (unsigned int)(y * a.W + x);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+                    float v = 0.f;
+                    if (inb && co < a.cout) v = res[(unsigned int)co * uplane + pix];
+                    acc[q][m][r] = v;
+                }
+        }
+    };
+    load_w(0, 0, wa);
     fetch_tile(0);
-    fetch_w(0, 0);
+    init_acc(0);
     store_tile();
-    int wbuf = 0;
     for (int stage = 0; stage < n_stages; ++stage) {
         const int k = stage / n_chunks, chunk = stage - k * n_chunks;
-        const int cc = (a.cin - chunk * kConvChunk) < kConvChunk ? (a.cin - chunk * kConvChunk) : kConvChunk;
-        const int ccp = (cc + 1) >> 1;
         if (chunk == 0) {
+            // the accumulators were pre-loaded with the residual (or zero) by init_acc(); add the bias here, so
+            // that the epilogue has no load to wait for
 #pragma unroll
-            for (int q = 0; q < RPW; ++q)
+            for (int m = 0; m < MT; ++m) {
+                float bv[16];
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
+                for (int r = 0; r < 16; ++r) bv[r] = a.bias[m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl];   // padded
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[q][m][r] = 0.f;
+                for (int q = 0; q < RPW; ++q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[q][m][r] += bv[r];
+            }
         }
-        store_w(wbuf);
-        __syncthreads();                                   // this stage's tile and tap-0 weights are visible
+        CT_PHASE(0);                                       // store_tile + acc init of the previous iteration
+        __syncthreads();                                   // this stage's tile is visible
+        CT_PHASE(1);
         const bool next_stage = (stage + 1 < n_stages);
-        if (next_stage) fetch_tile(stage + 1);            // the next halo tile: in flight under this stage's MFMAs
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const bool last_tap = (tap + 1 == TAPS);
-            if (!last_tap) fetch_w(chunk, tap + 1);
-            else if (next_stage) fetch_w((chunk + 1 == n_chunks) ? 0 : chunk + 1, 0);
+        const int next_chunk = (chunk + 1 == n_chunks) ? 0 : chunk + 1;
+        auto compute_tap = [&](int tap, const float (&w)[KSTEPS][MT]) {
             const int ky = tap / KS, kx = tap - ky * KS;
             const float *brow = tin + hl * CS + (wave * RPW + ky) * TWP + kx + nl;
-            const float *arow = tw0 + wbuf * WSLICE + hl * COUTP + nl;
-            auto kstep = [&](int p) {
-                float w[MT];
+            // B operands are read one k-step ahead of the MFMAs that consume them, and the scheduler is
+            // pinned to "1 LDS read, then RPW*MT MFMAs" groups: a wave that has the matrix pipe to itself
+            // (partner in its epilogue) then issues back to back instead of exposing the LDS latency per step
+            float bc[RPW], bn[RPW];
 #pragma unroll
-                for (int m = 0; m < MT; ++m) w[m] = arow[p * 2 * COUTP + m * 32];
+            for (int q = 0; q < RPW; ++q) bc[q] = brow[q * TWP];
 #pragma unroll
-                for (int q = 0; q < RPW; ++q) {
-                    const float b = brow[p * 2 * CS + q * TWP];
+            for (int p = 0; p < KSTEPS; ++p) {
+                if (p + 1 < KSTEPS) {
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[m], b, acc[q][m], 0, 0, 0);
+                    for (int q = 0; q < RPW; ++q) bn[q] = brow[(p + 1) * 2 * CS + q * TWP];
                 }
-            };
-            if (ccp == kConvChunk / 2) {   // the common full chunk: compile-time trip count, fully unrolled
 #pragma unroll
-                for (int p = 0; p < kConvChunk / 2; ++p) kstep(p);
-            } else {
-                for (int p = 0; p < ccp; ++p) kstep(p);
+                for (int q = 0; q < RPW; ++q)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[p][m], bc[q], acc[q][m], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < RPW; ++q) bc[q] = bn[q];
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // the (paired) LDS read of step p+1
+                __builtin_amdgcn_sched_group_barrier(0x008, RPW * MT, 0);   // the MFMAs of step p
             }
-            wbuf ^= 1;
-            if (!last_tap) {
-                store_w(wbuf);             // the other buffer: nobody reads it during this tap
-                __syncthreads();
+        };
+        // taps alternate between the two weight register sets; the set not in use is being loaded
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const bool last_tap = (tap + 1 == TAPS);
+            if ((tap & 1) == 0) {
+                if (!last_tap) load_w(chunk, tap + 1, wb);
+                else if (next_stage) load_w(next_chunk, 0, wb);
+                if (tap == 0 && next_stage) fetch_tile(stage + 1);   // next halo tile: in flight under this stage's MFMAs
+                compute_tap(tap, wa);
+            } else {
+                if (!last_tap) load_w(chunk, tap + 1, wa);
+                else if (next_stage) load_w(next_chunk, 0, wa);
+                compute_tap(tap, wb);
             }
         }
+        if ((TAPS & 1) == 1) {   // odd tap count: the next stage's tap-0 weights sit in wb; move them to wa
+#pragma unroll
+            for (int p = 0; p < KSTEPS; ++p)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) wa[p][m] = wb[p][m];
+        }
+        CT_PHASE(2);                                       // tap loop (MFMAs + prefetch issue)
         if (chunk + 1 == n_chunks) {
             // ---- epilogue: lane owns pixels (y0 + wave*RPW + q, x0+nl), channels (r&3)+8(r>>2)+4hl of each 32-tile ----
             const int t = blockIdx.x + k * gridDim.x;
@@ -188,36 +251,45 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
                 const int y = ty * kConvTH + wave * RPW + q;
                 if (y < a.H && x < a.W) {
                     // 32-bit element offsets inside one image (cout * plane < 2^32): keeps the 64 stores cheap in registers
-                    float *out = a.out + (size_t)n * a.out_bstride;
-                    const float *res = a.residual ? a.residual + (size_t)n * a.res_bstride : nullptr;
+                    float *__restrict__ out = a.out + (size_t)n * a.out_bstride;
+                    const float *__restrict__ res = a.residual ? a.residual + (size_t)n * a.res_bstride : nullptr;
                     const unsigned int pix = (unsigned int)(y * a.W + x);
+                    const bool full = (a.cout == COUTP);   // uniform: no per-channel predicate in the common case
+                    const bool late_res = (res != nullptr) && !res_in_acc;   // LeakyReLU *and* a skip: not in this model
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-                            if (co < a.cout) {
-                                const unsigned int off = (unsigned int)co * uplane + pix;
-                                float v = acc[q][m][r] + a.bias[co];
-                                if (a.act == 1) v = v > 0.f ? v : 0.01f * v;
-                                if (res) v += res[off];
-                                if (a.clamp) v = fminf(fmaxf(v, 0.f), 1.f);
-                                out[off] = v;
-                            }
+                            float v = acc[q][m][r];
+                            if (a.act == 1) v = v > 0.f ? v : 0.01f * v;
+                            if (late_res && (full || co < a.cout)) v += res[(unsigned int)co * uplane + pix];
+                            if (a.clamp) v = fminf(fmaxf(v, 0.f), 1.f);
+                            if (full || co < a.cout) out[(unsigned int)co * uplane + pix] = v;
                         }
                     }
                 }
             }
+            if (next_stage) init_acc(k + 1);   // the stores above are fire-and-forget; start the next tile's skip loads
         }
+        CT_PHASE(3);                       // epilogue
         __syncthreads();                   // every wave is done reading this stage's tile
+        CT_PHASE(4);
         if (next_stage) store_tile();      // waits for the prefetched loads, then fills the tile
     }
+#ifdef CT_CONV_PROFILE
+    CT_PHASE(0);
+    if (tid == 0 && a.prof) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a.prof[(size_t)blockIdx.x * 8 + i] = pt[i];
+    }
+#endif
 }
 
 template <int KS, int MT>
 static int launch_conv(const ConvArgs &a, int N, hipStream_t s) {
     constexpr int ROWS = kConvTH + KS - 1, TWP = kConvTW + KS - 1;
-    const size_t lds = (size_t)(kConvChunk * ROWS * TWP + 2 * (kConvChunk / 2) * 2 * MT * 32) * sizeof(float);
+    const size_t lds = (size_t)(kConvChunk * ROWS * TWP) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<KS, MT>),
@@ -417,12 +489,25 @@ int ct_conv2d_f32(const float *in, const float *wp, const float *bias, const flo
     a.in = in; a.wp = wp; a.bias = bias; a.residual = residual; a.out = out;
     a.cin = cin; a.cout = cout; a.H = h; a.W = w;
     a.in_bstride = in_bstride; a.out_bstride = out_bstride; a.res_bstride = res_bstride;
-    a.act = act; a.clamp = clamp;
+    a.act = act; a.clamp = clamp; a.prof = nullptr;
     hipStream_t s = (hipStream_t)stream;
     const int mt = cout > 32 ? 2 : 1;
     if (ksize == 3) return mt == 2 ? ct::launch_conv<3, 2>(a, n, s) : ct::launch_conv<3, 1>(a, n, s);
     return mt == 2 ? ct::launch_conv<1, 2>(a, n, s) : ct::launch_conv<1, 1>(a, n, s);
 }
+
+#ifdef CT_CONV_PROFILE
+// diagnostic build only (tools/prof_conv.py): 3x3 64->64 conv with per-phase cycle stamps, prof[grid][8]
+int ct_conv2d_prof_f32(const float *in, const float *wp, const float *bias, const float *residual, float *out, int n,
+                       int cin, int cout, int h, int w, unsigned long long *prof, void *stream) {
+    ct::ConvArgs a;
+    a.in = in; a.wp = wp; a.bias = bias; a.residual = residual; a.out = out;
+    a.cin = cin; a.cout = cout; a.H = h; a.W = w;
+    a.in_bstride = (long long)cin * h * w; a.out_bstride = (long long)cout * h * w; a.res_bstride = a.out_bstride;
+    a.act = 0; a.clamp = 0; a.prof = prof;
+    return ct::launch_conv<3, 2>(a, n, (hipStream_t)stream);
+}
+#endif
 
 size_t ct_pam_workspace_bytes(int n, int h, int w) {
     if (n < 0 || h < 0 || w < 0) return 0;
