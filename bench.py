@@ -172,13 +172,21 @@ def main():
                 lambda: lin.monge_kantorovitch_color_transfer_cuda(tgt[0], ref[0]))
             extra["xiao_pairs_per_s_f64out_hostalgebra"] = rate(
                 lambda: lin.color_transfer_in_correlated_color_space_cuda(tgt[0], ref[0]))
-            try:
-                import methods.iterative as it
-                rots = it.draw_rotations(4, seed=0)
-                extra["idt_pairs_per_s_f64"] = rate(
-                    lambda: it.iterative_distribution_transfer_cuda(tgt[0], ref[0], rotations=rots), n=5)
-            except Exception as e:  # IDT is a later milestone; never hide the reason
-                extra["idt_pairs_per_s_f64"] = "unavailable: %s" % (e,)
+            import methods.iterative as it
+            rots = it.draw_rotations(4, seed=0)
+            idt = rate(lambda: it.iterative_distribution_transfer_cuda(tgt[0], ref[0], rotations=rots), n=5)
+            extra["idt_pairs_per_s_f64"] = idt
+            extra["idt_frac_hbm_peak"] = 920678400 * idt / HBM_PEAK      # float64 working image
+            # configs[2]: DCMCS3DI forward, random init, 512x512, exact-f32 MFMA (peak 157.3 TFLOP/s)
+            from methods.dcmcs3di import DCMCS3DI
+            torch.manual_seed(0)
+            net = DCMCS3DI().to(device).eval()
+            l512, r512 = torch.rand(1, 3, 512, 512, device=device), torch.rand(1, 3, 512, 512, device=device)
+            dc = rate(lambda: net(l512, r512, inference=True), n=5)
+            flop = 512 * 512 * (6591040 + 390 * 512)
+            extra["dcmcs3di_512_pairs_per_s_f32"] = dc
+            extra["dcmcs3di_512_tflops"] = flop * dc / 1e12
+            extra["dcmcs3di_512_frac_fp32_mfma_peak"] = flop * dc / 157.3e12
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,50 @@
+"""`Runner` -- the plugin loader of the reference (methods/__init__.py:10-40) without Lightning.
+
+`Runner(func_spec)` resolves a dotted path "pkg.mod.func" with importlib exactly like the reference
+(methods/__init__.py:14-16); `forward(batch)` applies it to every sample of the batch
+(methods/__init__.py:18-27) and `test_step` clamps and scores the result (methods/__init__.py:29-40;
+PSNR here -- SSIM/FSIM/iCID are third-party `piq`/`kornia` code).
+
+If the resolved module also offers a device-resident variant `<func>_cuda`, the batch never leaves
+the GPU; otherwise the numpy callable is used through the same host round trip as the reference.
+"""
+import importlib
+
+import torch
+
+
+def psnr(x, y, data_range=1.0):
+    """Peak signal-to-noise ratio per sample, [B] (piq.psnr semantics: mean over C,H,W, then -10 log10)."""
+    mse = ((x.double() - y.double()) ** 2).flatten(1).mean(dim=1)
+    return 10.0 * torch.log10(data_range ** 2 / mse.clamp_min(1e-300))
+
+
+class Runner(torch.nn.Module):
+    def __init__(self, func_spec):
+        super().__init__()
+        specs = func_spec.split(".")
+        module, func = ".".join(specs[:-1]), specs[-1]
+        mod = importlib.import_module(module)
+        self.func = getattr(mod, func)
+        self.func_cuda = getattr(mod, func + "_cuda", None)
+        self.func_spec = func_spec
+
+    def forward(self, batch):
+        target, reference = batch["target"], batch["reference"]
+        if self.func_cuda is not None and target.is_cuda:
+            # [B,3,H,W] -> HWC on the device; one call per sample like the reference's loop (so that e.g. IDT draws
+            # fresh rotations per sample exactly as methods/__init__.py:20-25 + iterative.py:32 do)
+            t = target.permute(0, 2, 3, 1).contiguous()
+            r = reference.permute(0, 2, 3, 1).contiguous()
+            out = torch.stack([self.func_cuda(a, b) for a, b in zip(t, r)])
+            return out.float().permute(0, 3, 1, 2)
+        outputs = []
+        for t, r in zip(target, reference):
+            t = t.permute(1, 2, 0).detach().cpu().numpy()
+            r = r.permute(1, 2, 0).detach().cpu().numpy()
+            outputs.append(torch.from_numpy(self.func(t, r)).float().permute(2, 0, 1))
+        return torch.stack(outputs).to(target.device)
+
+    def test_step(self, batch, batch_idx=0, dataloader_idx=0):
+        result = self(batch).clamp(0, 1)
+        return {"Test PSNR": psnr(result, batch["gt"].to(result.device))}

@@ -1,0 +1,81 @@
+"""`python -m utils.cli test --config <yaml> [--model.func_spec ...] [--data.n_frames N] [--ckpt_path P]`
+
+A minimal look-alike of the reference's LightningCLI entry point (utils/cli.py:1-3, README.md:69-71) for the
+`test` sub-command only (Lightning/jsonargparse are not part of this stack): YAML with `class_path/init_args`
+for model and data, dotted `--section.key value` overrides, `trainer.*` keys accepted and ignored.  Frames are
+sharded over ranks when launched with torch.distributed.run (frame f -> rank f % world) and the per-frame
+metrics are gathered with ONE collective (utils/sharding.py); rank 0 prints the reference's `Test PSNR`.
+"""
+import importlib
+import os
+import sys
+
+import torch
+import yaml
+
+
+def _set(cfg, dotted, value):
+    keys = dotted.split(".")
+    node = cfg
+    for k in keys[:-1]:
+        node = node.setdefault(k, {})
+        if k in ("model", "data") and "init_args" in node and keys[-1] not in ("class_path",):
+            node = node["init_args"]
+    node[keys[-1]] = yaml.safe_load(value)
+
+
+def _instantiate(section):
+    module, cls = section["class_path"].rsplit(".", 1)
+    return getattr(importlib.import_module(module), cls)(**section.get("init_args", {}))
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if not argv or argv[0] != "test":
+        raise SystemExit("only the `test` sub-command exists here (fit/validate/predict are Lightning training paths)")
+    cfg, ckpt, i = {}, None, 1
+    while i < len(argv):
+        key, val = argv[i], argv[i + 1]
+        if key == "--config":
+            with open(val) as fh:
+                cfg = yaml.safe_load(fh) or {}
+        elif key == "--ckpt_path":
+            ckpt = val
+        elif key.startswith("--"):
+            _set(cfg, key[2:], val)
+        i += 2
+    import torch.distributed as dist
+    from utils import sharding as sh
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    model = _instantiate(cfg["model"]).to(device).eval()
+    if ckpt:
+        model.load_state_dict(torch.load(ckpt, map_location=device)["state_dict"], strict=True)
+    data_cfg = dict(cfg.get("data", {}))
+    data_cfg["class_path"] = "utils.data.DataModule"
+    frames = _instantiate(data_cfg).test_frames()
+    mine = sh.frames_of_rank(len(frames), rank, world)
+    rows = []
+    for f in mine:
+        batch = {k: v.unsqueeze(0).to(device) for k, v in frames[f].items()}
+        if hasattr(model, "test_step"):
+            rows.append(model.test_step(batch, f)["Test PSNR"].reshape(1))
+        else:                                   # CNN modules: forward(target, reference, inference=True)
+            from methods import psnr
+            corrected, _ = model(batch["target"], batch["reference"], inference=True)
+            rows.append(psnr(corrected, batch["gt"]).reshape(1))
+    local = torch.stack(rows).double() if rows else torch.zeros((0, 1), dtype=torch.float64, device=device)
+    table = sh.gather_frame_metrics(local, len(frames), rank, world)
+    if rank == 0:
+        print("Test PSNR: %.4f  (%d frames, %d GPU%s)" % (float(table.mean()), len(frames), world, "" if world == 1 else "s"))
+    if world > 1:
+        dist.destroy_process_group()
+    return table
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,46 @@
+"""Frame sharding of a stereo video across the GPUs of one node.
+
+Frames are independent units (the reference's Runner loops samples independently,
+methods/__init__.py:20-25): frame f belongs to rank f % world.  Each rank keeps a
+[n_local, n_metrics] tensor of per-frame metrics; ONE collective at the end
+(all_gather_into_tensor; backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests)
+reassembles the [n_frames, n_metrics] table in frame order on every rank.  Seeds are derived from
+the FRAME index, never from the rank, so results are identical for any world size.
+"""
+import torch
+import torch.distributed as dist
+
+
+def frames_of_rank(n_frames, rank, world):
+    """Frame indices owned by `rank`: rank, rank + world, ..."""
+    return list(range(rank, n_frames, world))
+
+
+def padded_local_count(n_frames, world):
+    """Every rank contributes the same number of rows to the gather (pad with NaN rows)."""
+    return (n_frames + world - 1) // world
+
+
+def frame_seed(frame_index, base=1234):
+    """Seed of the synthetic frame / of the IDT rotations of frame `frame_index` (world-size independent)."""
+    return base + int(frame_index)
+
+
+def gather_frame_metrics(local_metrics, n_frames, rank=None, world=None):
+    """local_metrics: [n_local, n_metrics] for frames_of_rank(...) in that order.
+    Returns [n_frames, n_metrics] in frame order on every rank (a single all_gather)."""
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    n_pad = padded_local_count(n_frames, world)
+    n_metrics = local_metrics.shape[1]
+    buf = torch.full((n_pad, n_metrics), float("nan"), dtype=local_metrics.dtype, device=local_metrics.device)
+    buf[: local_metrics.shape[0]] = local_metrics
+    if world == 1:
+        return buf[:n_frames]
+    out = torch.empty((world, n_pad, n_metrics), dtype=local_metrics.dtype, device=local_metrics.device)
+    dist.all_gather_into_tensor(out.view(world * n_pad, n_metrics), buf)
+    # rank r, slot i  ->  frame r + i * world
+    table = out.permute(1, 0, 2).reshape(world * n_pad, n_metrics)
+    return table[:n_frames]
