@@ -48,19 +48,25 @@ struct ConvArgs {
     unsigned long long *prof;   // diagnostic builds only (CT_CONV_PROFILE); NULL otherwise
 };
 
-template <int KS, int MT>
+template <int KS, int MT, bool VEC>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles_x, int tiles_y, int n_tiles) {
     constexpr int PAD = KS / 2;
+    constexpr bool HALO = (KS == 3);
     constexpr int ROWS = kConvTH + KS - 1;
-    constexpr int TWP = kConvTW + KS - 1;
-    constexpr int CS = ROWS * TWP;             // floats per channel in the LDS tile
-    constexpr int ELEMS = kConvChunk * CS;     // floats of one staged (tile, channel chunk)
-    constexpr int PF = (ELEMS + 255) / 256;    // prefetch registers per thread (85 for 3x3, 64 for 1x1)
+    constexpr int TWP = HALO ? kConvTW + 8 : kConvTW;   // LDS row = image columns [x0-4, x0+36): the 32 centre columns are 16-byte aligned
+    constexpr int COL0 = HALO ? 4 : 0;                  // LDS column of image column x0
+    constexpr int CS = ROWS * TWP;                      // floats per channel in the LDS tile
+    constexpr int NV4 = kConvChunk * ROWS * (kConvTW / 4);   // centre float4 of one staged (tile, 32-channel chunk)
+    constexpr int PF4 = NV4 / 256;                      // 10 (3x3) / 8 (1x1) per thread, exact
+    constexpr int NE = HALO ? kConvChunk * ROWS * 2 : 0;     // the two halo columns x0-1 and x0+32
+    constexpr int PFE = (NE + 255) / 256;               // 3 / 0
+    static_assert(NV4 % 256 == 0, "tile geometry");
     constexpr int COUTP = MT * 32;
     constexpr int RPW = kConvTH / 4;           // output rows per wave
     constexpr int TAPS = KS * KS;
     extern __shared__ float smem[];
     float *tin = smem;                         // [kConvChunk][ROWS][TWP]
+    float *stg = smem + kConvChunk * CS + (threadIdx.x >> 6) * (32 * 32);   // per-wave [32 ch][32 px] transpose buffer
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, hl = lane >> 5;
     const size_t plane = (size_t)a.H * a.W;
@@ -70,8 +76,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
     const int n_stages = my_tiles * n_chunks;  // a stage = (tile, channel chunk)
 
     // ---- (tile, chunk) halo tile -> registers; the loads stay in flight while the previous stage computes ----
-    // Offsets are 32-bit relative to the (image, chunk) base: a chunk spans < 2^31 elements.
-    float pf[PF];
+    // Centre columns as 16-byte loads (a 4-byte-per-lane load costs ~620 cycles per wave-instruction on this chip,
+    // tools/ubench/store_rates.hip), the two halo columns as scalars.  Offsets are 32-bit relative to the chunk base.
+    float4 pf4[PF4];
+    float pfe[PFE > 0 ? PFE : 1];
     const unsigned int uplane = (unsigned int)plane;
     auto fetch_tile = [&](int stage) {
         const int k = stage / n_chunks, chunk = stage - k * n_chunks;
@@ -81,28 +89,61 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
         const int cc = (a.cin - c0) < kConvChunk ? (a.cin - c0) : kConvChunk;
         const float *in = a.in + (size_t)n * a.in_bstride + (size_t)c0 * plane;
 #pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            {
-                int e = tid + i * 256;
-                // opaque to the optimiser: otherwise LICM hoists all PF index decompositions (c, yy, xx are
-                // stage-invariant) out of the stage loop and keeps 3*PF values alive -> hundreds of spills
+        for (int i = 0; i < PF4; ++i) {
+            int f = tid + i * 256;
+            // opaque to the optimiser: otherwise LICM hoists all index decompositions (stage-invariant) out of the
+            // stage loop and keeps them alive -> hundreds of spills
+            asm volatile("" : "+v"(f));
+            const int c = f / (ROWS * 8), rem = f - c * (ROWS * 8);
+            const int yy = rem >> 3, g = rem & 7;
+            const int gy = y0 + yy - PAD, gx = x0 + 4 * g;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < cc && gy >= 0 && gy < a.H) {
+                const float *p = in + (unsigned int)c * uplane + (unsigned int)(gy * a.W + gx);
+                if (VEC) {
+                    if (gx < a.W) v = *reinterpret_cast<const float4 *>(p);   // W % 4 == 0: all four columns or none
+                } else {
+                    if (gx + 0 < a.W) v.x = p[0];
+                    if (gx + 1 < a.W) v.y = p[1];
+                    if (gx + 2 < a.W) v.z = p[2];
+                    if (gx + 3 < a.W) v.w = p[3];
+                }
+            }
+            pf4[i] = v;
+        }
+        if (HALO) {
+#pragma unroll
+            for (int j = 0; j < PFE; ++j) {
+                int e = tid + j * 256;
                 asm volatile("" : "+v"(e));
-                const int c = e / CS, rem = e - c * CS;
-                const int yy = rem / TWP, xx = rem - yy * TWP;
-                const int gy = y0 + yy - PAD, gx = x0 + xx - PAD;
-                const bool ok = (e < ELEMS) && (c < cc) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                // exec-masked load into a pre-zeroed register: no predicate has to outlive the load
+                const int c = e / (ROWS * 2), rem = e - c * (ROWS * 2);
+                const int yy = rem >> 1, side = rem & 1;
+                const int gy = y0 + yy - PAD, gx = side ? x0 + kConvTW : x0 - 1;
                 float v = 0.f;
-                if (ok) v = in[(unsigned int)c * uplane + (unsigned int)(gy * a.W + gx)];
-                pf[i] = v;
+                if (e < NE && c < cc && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                    v = in[(unsigned int)c * uplane + (unsigned int)(gy * a.W + gx)];
+                pfe[j] = v;
             }
         }
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            const int e = tid + i * 256;
-            if (e < ELEMS) tin[e] = pf[i];
+        for (int i = 0; i < PF4; ++i) {
+            int f = tid + i * 256;
+            asm volatile("" : "+v"(f));
+            const int c = f / (ROWS * 8), rem = f - c * (ROWS * 8);
+            const int yy = rem >> 3, g = rem & 7;
+            *reinterpret_cast<float4 *>(tin + c * CS + yy * TWP + COL0 + 4 * g) = pf4[i];
+        }
+        if (HALO) {
+#pragma unroll
+            for (int j = 0; j < PFE; ++j) {
+                int e = tid + j * 256;
+                asm volatile("" : "+v"(e));
+                const int c = e / (ROWS * 2), rem = e - c * (ROWS * 2);
+                const int yy = rem >> 1, side = rem & 1;
+                if (e < NE) tin[c * CS + yy * TWP + (side ? COL0 + kConvTW : COL0 - 1)] = pfe[j];
+            }
         }
     };
     // ---- A operand: this lane's weights of one (tap, chunk) slice, straight from L1/L2 into registers ----
@@ -148,26 +189,68 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
     // accumulator pre-load for tile k: residual (ResB skip, act == 0) or zero.  Issued right after the previous
     // tile's stores, i.e. a whole barrier + tile-store phase before the first MFMA needs it.
     const bool res_in_acc = (a.residual != nullptr) && (a.act == 0);
+    // The accumulator of a lane holds 16 channels of ONE pixel, so a direct gather of the skip tensor (and the
+    // final scatter of the result) would be 4-byte-per-lane accesses -- ~620 cycles per wave-instruction on this chip
+    // (tools/ubench/store_rates.hip).  With VEC both go through a per-wave 32x32 LDS transpose instead: global
+    // traffic is 16 bytes per lane (8 channel rows x 128 B per instruction), LDS does the re-layout.
     auto init_acc = [&](int k) {
         const int t = blockIdx.x + k * gridDim.x;
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
-        const int x = tx * kConvTW + nl;
         const float *__restrict__ res = res_in_acc ? a.residual + (size_t)n * a.res_bstride : nullptr;
+        if (VEC) {
+            // raw float4 rows land in the accumulator registers; finish_acc() re-lays them out at tile start
+            const int x4 = tx * kConvTW + 4 * (lane & 7);
 #pragma unroll
-        for (int q = 0; q < RPW; ++q) {
-            const int y = ty * kConvTH + wave * RPW + q;
-            const bool inb = res_in_acc && (y < a.H) && (x < a.W);
-            const unsigned int pix = (unsigned int)(y * a.W + x);
+            for (int q = 0; q < RPW; ++q) {
+                const int y = ty * kConvTH + wave * RPW + q;
+                const bool inb = res_in_acc && (y < a.H) && (x4 < a.W);
+                const unsigned int pix = (unsigned int)(y * a.W + x4);
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+                for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-                    float v = 0.f;
-                    if (inb && co < a.cout) v = res[(unsigned int)co * uplane + pix];
-                    acc[q][m][r] = v;
-                }
+                    for (int j = 0; j < 4; ++j) {
+                        const int co = m * 32 + (lane >> 3) + 8 * j;
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (inb && co < a.cout) v = *reinterpret_cast<const float4 *>(res + (unsigned int)co * uplane + pix);
+                        acc[q][m][4 * j + 0] = v.x; acc[q][m][4 * j + 1] = v.y;
+                        acc[q][m][4 * j + 2] = v.z; acc[q][m][4 * j + 3] = v.w;
+                    }
+            }
+        } else {
+            const int x = tx * kConvTW + nl;
+#pragma unroll
+            for (int q = 0; q < RPW; ++q) {
+                const int y = ty * kConvTH + wave * RPW + q;
+                const bool inb = res_in_acc && (y < a.H) && (x < a.W);
+                const unsigned int pix = (unsigned int)(y * a.W + x);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+                        float v = 0.f;
+                        if (inb && co < a.cout) v = res[(unsigned int)co * uplane + pix];
+                        acc[q][m][r] = v;
+                    }
+            }
         }
+    };
+    // VEC: [8j + lane/8][4*(lane%8)..+3] rows -> (pixel nl, channels (r&3)+8(r>>2)+4hl) accumulator layout
+    auto finish_acc = [&]() {
+        if (!VEC) return;
+#pragma unroll
+        for (int q = 0; q < RPW; ++q)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<float4 *>(stg + ((lane >> 3) + 8 * j) * 32 + 4 * (lane & 7)) =
+                        make_float4(acc[q][m][4 * j], acc[q][m][4 * j + 1], acc[q][m][4 * j + 2], acc[q][m][4 * j + 3]);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][m][r] = stg[((r & 3) + 8 * (r >> 2) + 4 * hl) * 32 + nl];
+                __builtin_amdgcn_wave_barrier();
+            }
     };
     load_w(0, 0, wa);
     fetch_tile(0);
@@ -176,6 +259,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
     for (int stage = 0; stage < n_stages; ++stage) {
         const int k = stage / n_chunks, chunk = stage - k * n_chunks;
         if (chunk == 0) {
+            finish_acc();
             // the accumulators were pre-loaded with the residual (or zero) by init_acc(); add the bias here, so
             // that the epilogue has no load to wait for
 #pragma unroll
@@ -196,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
         const int next_chunk = (chunk + 1 == n_chunks) ? 0 : chunk + 1;
         auto compute_tap = [&](int tap, const float (&w)[KSTEPS][MT]) {
             const int ky = tap / KS, kx = tap - ky * KS;
-            const float *brow = tin + hl * CS + (wave * RPW + ky) * TWP + kx + nl;
+            const float *brow = tin + hl * CS + (wave * RPW + ky) * TWP + (COL0 - PAD) + kx + nl;
             // B operands are read one k-step ahead of the MFMAs that consume them, and the scheduler is
             // pinned to "1 LDS read, then RPW*MT MFMAs" groups: a wave that has the matrix pipe to itself
             // (partner in its epilogue) then issues back to back instead of exposing the LDS latency per step
@@ -245,27 +329,50 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
             // ---- epilogue: lane owns pixels (y0 + wave*RPW + q, x0+nl), channels (r&3)+8(r>>2)+4hl of each 32-tile ----
             const int t = blockIdx.x + k * gridDim.x;
             const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
-            const int x = tx * kConvTW + nl;
+            float *__restrict__ out = a.out + (size_t)n * a.out_bstride;
+            const float *__restrict__ res = a.residual ? a.residual + (size_t)n * a.res_bstride : nullptr;
+            const bool late_res = (res != nullptr) && !res_in_acc;   // LeakyReLU *and* a skip: not in this model
+            const bool full = (a.cout == COUTP);   // uniform: no per-channel predicate in the common case
+            const bool wide = VEC && !late_res && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
 #pragma unroll
             for (int q = 0; q < RPW; ++q) {
                 const int y = ty * kConvTH + wave * RPW + q;
-                if (y < a.H && x < a.W) {
-                    // 32-bit element offsets inside one image (cout * plane < 2^32): keeps the 64 stores cheap in registers
-                    float *__restrict__ out = a.out + (size_t)n * a.out_bstride;
-                    const float *__restrict__ res = a.residual ? a.residual + (size_t)n * a.res_bstride : nullptr;
-                    const unsigned int pix = (unsigned int)(y * a.W + x);
-                    const bool full = (a.cout == COUTP);   // uniform: no per-channel predicate in the common case
-                    const bool late_res = (res != nullptr) && !res_in_acc;   // LeakyReLU *and* a skip: not in this model
+                if (wide) {
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
                             float v = acc[q][m][r];
                             if (a.act == 1) v = v > 0.f ? v : 0.01f * v;
-                            if (late_res && (full || co < a.cout)) v += res[(unsigned int)co * uplane + pix];
                             if (a.clamp) v = fminf(fmaxf(v, 0.f), 1.f);
-                            if (full || co < a.cout) out[(unsigned int)co * uplane + pix] = v;
+                            stg[((r & 3) + 8 * (r >> 2) + 4 * hl) * 32 + nl] = v;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        const int x4 = tx * kConvTW + 4 * (lane & 7);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int co = m * 32 + (lane >> 3) + 8 * j;
+                            const float4 v = *reinterpret_cast<const float4 *>(stg + ((lane >> 3) + 8 * j) * 32 + 4 * (lane & 7));
+                            if (y < a.H && x4 < a.W && (full || co < a.cout))
+                                *reinterpret_cast<float4 *>(out + (unsigned int)co * uplane + (unsigned int)(y * a.W + x4)) = v;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                } else {
+                    const int x = tx * kConvTW + nl;
+                    if (y < a.H && x < a.W) {
+                        const unsigned int pix = (unsigned int)(y * a.W + x);
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+                                float v = acc[q][m][r];
+                                if (a.act == 1) v = v > 0.f ? v : 0.01f * v;
+                                if (late_res && (full || co < a.cout)) v += res[(unsigned int)co * uplane + pix];
+                                if (a.clamp) v = fminf(fmaxf(v, 0.f), 1.f);
+                                if (full || co < a.cout) out[(unsigned int)co * uplane + pix] = v;
+                            }
                         }
                     }
                 }
@@ -288,20 +395,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
 
 template <int KS, int MT>
 static int launch_conv(const ConvArgs &a, int N, hipStream_t s) {
-    constexpr int ROWS = kConvTH + KS - 1, TWP = kConvTW + KS - 1;
-    const size_t lds = (size_t)(kConvChunk * ROWS * TWP) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<KS, MT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    constexpr int ROWS = kConvTH + KS - 1, TWP = (KS == 3) ? kConvTW + 8 : kConvTW;
+    const size_t lds = (size_t)(kConvChunk * ROWS * TWP + 4 * 32 * 32) * sizeof(float);
+    // 16-byte loads need every (channel, row, 4-column group) address 16-byte aligned
+    const bool vec = (a.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.in) & 15) == 0) && (a.in_bstride % 4 == 0) &&
+                     ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0) && (a.out_bstride % 4 == 0) &&
+                     (!a.residual || (((reinterpret_cast<uintptr_t>(a.residual) & 15) == 0) && (a.res_bstride % 4 == 0)));
     const int tiles_x = (a.W + kConvTW - 1) / kConvTW, tiles_y = (a.H + kConvTH - 1) / kConvTH;
     const long long n_tiles = (long long)tiles_x * tiles_y * N;
     if (n_tiles > 0x7fffffffLL) return CT_E_BADARG;
     const int grid = n_tiles < 2 * kNumCUs ? (int)n_tiles : 2 * kNumCUs;   // persistent: two workgroups per CU
-    hipLaunchKernelGGL((conv_mfma_kernel<KS, MT>), dim3(grid), dim3(256), lds, s, a, tiles_x, tiles_y, (int)n_tiles);
+    if (vec) hipLaunchKernelGGL((conv_mfma_kernel<KS, MT, true>), dim3(grid), dim3(256), lds, s, a, tiles_x, tiles_y, (int)n_tiles);
+    else hipLaunchKernelGGL((conv_mfma_kernel<KS, MT, false>), dim3(grid), dim3(256), lds, s, a, tiles_x, tiles_y, (int)n_tiles);
     CT_CHECK_LAUNCH();
     return CT_OK;
 }
