@@ -430,44 +430,119 @@ struct PamArgs {
 };
 
 constexpr int kPamTQ = 32;   // queries per workgroup
+constexpr int kPamKC = 128;  // keys staged per S step (one 32-key MFMA tile per wave)
 constexpr int kPamJC = 64;   // keys staged per PV step
+constexpr int kPamC = 64;    // channels of q/k (DCMCS3DI: channels = 64)
+
+// Cooperative copy of rows [r][j0 .. j0+NCOLS) of a row-major [rows][plane-strided] slab into registers
+// (NV4 float4 per thread), 16-byte loads when the row base is aligned, zero fill outside [0,W) x [0,rows).
+template <int NROWS, int NCOLS>
+struct RowChunk {
+    static constexpr int V4_PER_ROW = NCOLS / 4;
+    static constexpr int NV4 = (NROWS * V4_PER_ROW + 255) / 256;
+    float4 v[NV4];
+    // src(r) = row pointer of row r at column 0, or nullptr for a zero row
+    template <typename RowPtr>
+    __device__ __forceinline__ void fetch(RowPtr src, int j0, int W, bool vec, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+            int f = tid + i * 256;
+            asm volatile("" : "+v"(f));
+            const int r = f / V4_PER_ROW, g = f - r * V4_PER_ROW;
+            const int j = j0 + 4 * g;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float *p = (r < NROWS) ? src(r) : nullptr;
+            if (p && j < W) {
+                if (vec) x = *reinterpret_cast<const float4 *>(p + j);
+                else {
+                    x.x = p[j];
+                    if (j + 1 < W) x.y = p[j + 1];
+                    if (j + 2 < W) x.z = p[j + 2];
+                    if (j + 3 < W) x.w = p[j + 3];
+                }
+            }
+            v[i] = x;
+        }
+    }
+    // LDS image [NROWS][LD]; LD % 4 == 0 -> one 16-byte store, else four scalar stores
+    template <int LD>
+    __device__ __forceinline__ void store(float *lds, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+            const int f = tid + i * 256;
+            const int r = f / V4_PER_ROW, g = f - r * V4_PER_ROW;
+            if (r < NROWS) {
+                float *d = lds + r * LD + 4 * g;
+                if (LD % 4 == 0) *reinterpret_cast<float4 *>(d) = v[i];
+                else { d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w; }
+            }
+        }
+    }
+};
 
 template <int MODE>
 __global__ __launch_bounds__(256) void pam_attend_kernel(PamArgs a) {
     extern __shared__ float smem[];
     const int W = a.W, SW = W | 1;                 // odd row stride: column reads are conflict free
+    constexpr int VST = kPamJC + 1;                // odd: the PV A-operand reads walk down a column
     float *S = smem;                               // [32][SW]
-    float *Vs = smem + kPamTQ * SW;                // [96][kPamJC + 1]
+    float *Qs = smem + kPamTQ * SW;                // [64][32]
+    float *Ks = Qs + kPamC * kPamTQ;               // [64][128]   (S phase)  /  Vs [96][65] (PV phase), aliased
+    float *Vs = Ks;
     const int i0 = blockIdx.x * kPamTQ, h = blockIdx.y, n = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, hl = lane >> 5;
     const size_t plane = (size_t)a.H * W;
-    const float *q = a.q + (size_t)n * a.C * plane + (size_t)h * W;
-    const float *k = a.k + (size_t)n * a.C * plane + (size_t)h * W;
-    const float inv_c = 1.0f / (float)a.C;
+    const float *q = a.q + (size_t)n * kPamC * plane + (size_t)h * W;
+    const float *k = a.k + (size_t)n * kPamC * plane + (size_t)h * W;
+    const float inv_c = 1.0f / (float)kPamC;
+    const bool vec = (W % 4 == 0) && (((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k)) & 15) == 0);
 
     // ---- S tile = Q^T K / C : M = query i (A = Q[c][i]), N = key j (B = K[c][j]), K = channels ----
     {
-        const int qi = i0 + nl;
-        const int ntile = (W + 31) / 32;
-        for (int jt = wave; jt < ntile; jt += 4) {
-            const int kj = jt * 32 + nl;
+        RowChunk<kPamC, kPamTQ> qc;
+        qc.fetch([&](int r) { return q + (size_t)r * plane; }, i0, W, vec, tid);
+        RowChunk<kPamC, kPamKC> kc;
+        kc.fetch([&](int r) { return k + (size_t)r * plane; }, 0, W, vec, tid);
+        qc.template store<kPamTQ>(Qs, tid);
+        kc.template store<kPamKC>(Ks, tid);
+        __syncthreads();
+        float qa[kPamC / 2];                        // this lane's A operands for all 32 k-steps
+#pragma unroll
+        for (int p = 0; p < kPamC / 2; ++p) qa[p] = Qs[(2 * p + hl) * kPamTQ + nl];
+        for (int j0 = 0; j0 < W; j0 += kPamKC) {
+            const bool more = (j0 + kPamKC < W);
+            if (more) kc.fetch([&](int r) { return k + (size_t)r * plane; }, j0 + kPamKC, W, vec, tid);   // next chunk in flight
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            for (int c = 0; c < a.C; c += 2) {
-                const int ch = c + hl;
-                const float av = (qi < W && ch < a.C) ? q[(size_t)ch * plane + qi] : 0.f;
-                const float bv = (kj < W && ch < a.C) ? k[(size_t)ch * plane + kj] : 0.f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-            }
-            // D[i][j]: lane holds key column j = jt*32+nl, query rows (r&3)+8(r>>2)+4hl
+            const float *brow = Ks + hl * kPamKC + wave * 32 + nl;
+#pragma unroll
+            for (int p = 0; p < kPamC / 2; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[p], brow[p * 2 * kPamKC], acc, 0, 0, 0);
+            // D[i][j]: lane holds key column j, query rows (r&3)+8(r>>2)+4hl
+            const int kj = j0 + wave * 32 + nl;
             if (kj < W) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) S[((r & 3) + 8 * (r >> 2) + 4 * hl) * SW + kj] = acc[r] * inv_c;
             }
+            __syncthreads();                        // everyone is done with this K chunk
+            if (more) {
+                kc.template store<kPamKC>(Ks, tid);
+                __syncthreads();
+            }
         }
     }
-    __syncthreads();
+    // prefetch the first V chunk while the softmax runs (MODE 0)
+    const int CT = a.CV + 3;                        // feature channels + the 3 RGB channels of `right`
+    const float *v = MODE == 0 ? a.v + (size_t)n * a.CV * plane + (size_t)h * W : nullptr;
+    const float *rgb = MODE == 0 ? a.rgb + (size_t)n * 3 * plane + (size_t)h * W : nullptr;
+    const bool vecv = MODE == 0 && (W % 4 == 0) &&
+                      (((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(rgb)) & 15) == 0);
+    auto vrow = [&](int r) -> const float * {
+        return r < a.CV ? v + (size_t)r * plane : (r < CT ? rgb + (size_t)(r - a.CV) * plane : nullptr);
+    };
+    RowChunk<96, kPamJC> vc;
+    if (MODE == 0) vc.fetch(vrow, 0, W, vecv, tid);
+
     // ---- row softmax (F.softmax(dim=-1)): 8 rows per wave ----
     for (int rr = 0; rr < kPamTQ / 4; ++rr) {
         const int row = wave * (kPamTQ / 4) + rr;
@@ -505,26 +580,15 @@ __global__ __launch_bounds__(256) void pam_attend_kernel(PamArgs a) {
         return;
     }
     // ---- out[c][i] = sum_j V[c][j] P[i][j] : M = channel (A = V, staged [c][JC+1]), N = query (B = P) ----
-    const int CT = a.CV + 3;                        // feature channels + the 3 RGB channels of `right`
     const int mt_total = (CT + 31) / 32;            // 3 for CV = 64
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const float *v = a.v + (size_t)n * a.CV * plane + (size_t)h * W;
-    const float *rgb = a.rgb + (size_t)n * 3 * plane + (size_t)h * W;
-    constexpr int VST = kPamJC + 1;
+    vc.template store<VST>(Vs, tid);
+    __syncthreads();
     for (int j0 = 0; j0 < W; j0 += kPamJC) {
-        __syncthreads();
-        for (int idx = tid; idx < mt_total * 32 * kPamJC; idx += 256) {
-            const int c = idx / kPamJC, jj = idx - c * kPamJC, j = j0 + jj;
-            float val = 0.f;
-            if (j < W) {
-                if (c < a.CV) val = v[(size_t)c * plane + j];
-                else if (c < CT) val = rgb[(size_t)(c - a.CV) * plane + j];
-            }
-            Vs[c * VST + jj] = val;
-        }
-        __syncthreads();
+        const bool more = (j0 + kPamJC < W);
+        if (more) vc.fetch(vrow, j0 + kPamJC, W, vecv, tid);     // next chunk in flight under the MFMAs
         if (wave < mt_total) {
             const float *arow = Vs + (wave * 32 + nl) * VST + hl;
             const float *brow = S + nl * SW + j0 + hl;
@@ -533,6 +597,11 @@ __global__ __launch_bounds__(256) void pam_attend_kernel(PamArgs a) {
                 const float bv = (j0 + jj + hl < W) ? brow[jj] : 0.f;
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[jj], bv, acc, 0, 0, 0);
             }
+        }
+        __syncthreads();
+        if (more) {
+            vc.template store<VST>(Vs, tid);
+            __syncthreads();
         }
     }
     if (wave < mt_total) {
@@ -565,7 +634,9 @@ __global__ void pam_valid_kernel(const float *__restrict__ colpart, int tiles, i
 template <int MODE>
 static int launch_pam(const PamArgs &a, int N, hipStream_t s) {
     const int SW = a.W | 1;
-    const size_t lds = ((size_t)kPamTQ * SW + 96 * (kPamJC + 1)) * sizeof(float);
+    const size_t lds = ((size_t)kPamTQ * SW + kPamC * kPamTQ + kPamC * kPamKC) * sizeof(float);   // S + Q tile + K chunk (V chunk aliases it)
+    static_assert(96 * (kPamJC + 1) <= kPamC * kPamKC, "V chunk must fit the K chunk region");
+    if (a.C != kPamC) return CT_E_BADARG;
     if (lds > 160 * 1024) return CT_E_BADARG;
     static size_t attr = 0;
     if (lds > attr) {
