@@ -429,7 +429,6 @@ struct PamArgs {
     int C, CV, H, W;
 };
 
-constexpr int kPamTQ = 32;   // queries per workgroup
 constexpr int kPamKC = 128;  // keys staged per S step (one 32-key MFMA tile per wave)
 constexpr int kPamJC = 64;   // keys staged per PV step
 constexpr int kPamC = 64;    // channels of q/k (DCMCS3DI: channels = 64)
@@ -480,16 +479,18 @@ struct RowChunk {
     }
 };
 
-template <int MODE>
+// TQ = queries per workgroup: 32, or 16 for wide images (one TQ x W tile of S must fit the 160 KiB LDS; the MFMA
+// tile stays 32 x 32 with the upper 16 query rows idle)
+template <int MODE, int TQ>
 __global__ __launch_bounds__(256) void pam_attend_kernel(PamArgs a) {
     extern __shared__ float smem[];
     const int W = a.W, SW = W | 1;                 // odd row stride: column reads are conflict free
     constexpr int VST = kPamJC + 1;                // odd: the PV A-operand reads walk down a column
-    float *S = smem;                               // [32][SW]
-    float *Qs = smem + kPamTQ * SW;                // [64][32]
-    float *Ks = Qs + kPamC * kPamTQ;               // [64][128]   (S phase)  /  Vs [96][65] (PV phase), aliased
+    float *S = smem;                               // [TQ][SW]
+    float *Qs = smem + TQ * SW;                    // [64][TQ]
+    float *Ks = Qs + kPamC * TQ;               // [64][128]   (S phase)  /  Vs [96][65] (PV phase), aliased
     float *Vs = Ks;
-    const int i0 = blockIdx.x * kPamTQ, h = blockIdx.y, n = blockIdx.z;
+    const int i0 = blockIdx.x * TQ, h = blockIdx.y, n = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, hl = lane >> 5;
     const size_t plane = (size_t)a.H * W;
     const float *q = a.q + (size_t)n * kPamC * plane + (size_t)h * W;
@@ -499,16 +500,16 @@ __global__ __launch_bounds__(256) void pam_attend_kernel(PamArgs a) {
 
     // ---- S tile = Q^T K / C : M = query i (A = Q[c][i]), N = key j (B = K[c][j]), K = channels ----
     {
-        RowChunk<kPamC, kPamTQ> qc;
+        RowChunk<kPamC, TQ> qc;
         qc.fetch([&](int r) { return q + (size_t)r * plane; }, i0, W, vec, tid);
         RowChunk<kPamC, kPamKC> kc;
         kc.fetch([&](int r) { return k + (size_t)r * plane; }, 0, W, vec, tid);
-        qc.template store<kPamTQ>(Qs, tid);
+        qc.template store<TQ>(Qs, tid);
         kc.template store<kPamKC>(Ks, tid);
         __syncthreads();
         float qa[kPamC / 2];                        // this lane's A operands for all 32 k-steps
 #pragma unroll
-        for (int p = 0; p < kPamC / 2; ++p) qa[p] = Qs[(2 * p + hl) * kPamTQ + nl];
+        for (int p = 0; p < kPamC / 2; ++p) qa[p] = (nl < TQ) ? Qs[(2 * p + hl) * TQ + nl] : 0.f;
         for (int j0 = 0; j0 < W; j0 += kPamKC) {
             const bool more = (j0 + kPamKC < W);
             if (more) kc.fetch([&](int r) { return k + (size_t)r * plane; }, j0 + kPamKC, W, vec, tid);   // next chunk in flight
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(256) void pam_attend_kernel(PamArgs a) {
             const int kj = j0 + wave * 32 + nl;
             if (kj < W) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) S[((r & 3) + 8 * (r >> 2) + 4 * hl) * SW + kj] = acc[r] * inv_c;
+                for (int r = 0; r < TQ / 2; ++r) S[((r & 3) + 8 * (r >> 2) + 4 * hl) * SW + kj] = acc[r] * inv_c;   // rows < TQ
             }
             __syncthreads();                        // everyone is done with this K chunk
             if (more) {
@@ -544,8 +545,8 @@ __global__ __launch_bounds__(256) void pam_attend_kernel(PamArgs a) {
     if (MODE == 0) vc.fetch(vrow, 0, W, vecv, tid);
 
     // ---- row softmax (F.softmax(dim=-1)): 8 rows per wave ----
-    for (int rr = 0; rr < kPamTQ / 4; ++rr) {
-        const int row = wave * (kPamTQ / 4) + rr;
+    for (int rr = 0; rr < TQ / 4; ++rr) {
+        const int row = wave * (TQ / 4) + rr;
         float *srow = S + row * SW;
         float mx = -INFINITY;
         for (int j = lane; j < W; j += 64) mx = fmaxf(mx, srow[j]);
@@ -574,7 +575,7 @@ __global__ __launch_bounds__(256) void pam_attend_kernel(PamArgs a) {
         for (int j = tid; j < W; j += 256) {
             float s = 0.f;
 #pragma unroll
-            for (int r = 0; r < kPamTQ; ++r) s += S[r * SW + j];
+            for (int r = 0; r < TQ; ++r) s += S[r * SW + j];
             dst[j] = s;
         }
         return;
@@ -591,10 +592,10 @@ __global__ __launch_bounds__(256) void pam_attend_kernel(PamArgs a) {
         if (more) vc.fetch(vrow, j0 + kPamJC, W, vecv, tid);     // next chunk in flight under the MFMAs
         if (wave < mt_total) {
             const float *arow = Vs + (wave * 32 + nl) * VST + hl;
-            const float *brow = S + nl * SW + j0 + hl;
+            const float *brow = S + (nl < TQ ? nl : 0) * SW + j0 + hl;
 #pragma unroll
             for (int jj = 0; jj < kPamJC; jj += 2) {
-                const float bv = (j0 + jj + hl < W) ? brow[jj] : 0.f;
+                const float bv = (nl < TQ && j0 + jj + hl < W) ? brow[jj] : 0.f;
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[jj], bv, acc, 0, 0, 0);
             }
         }
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(256) void pam_attend_kernel(PamArgs a) {
     }
     if (wave < mt_total) {
         const int x = i0 + nl;
-        if (x < W) {
+        if (nl < TQ && x < W) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
@@ -631,24 +632,37 @@ __global__ void pam_valid_kernel(const float *__restrict__ colpart, int tiles, i
     if (colsum) colsum[o] = s;
 }
 
-template <int MODE>
-static int launch_pam(const PamArgs &a, int N, hipStream_t s) {
-    const int SW = a.W | 1;
-    const size_t lds = ((size_t)kPamTQ * SW + kPamC * kPamTQ + kPamC * kPamKC) * sizeof(float);   // S + Q tile + K chunk (V chunk aliases it)
-    static_assert(96 * (kPamJC + 1) <= kPamC * kPamKC, "V chunk must fit the K chunk region");
-    if (a.C != kPamC) return CT_E_BADARG;
-    if (lds > 160 * 1024) return CT_E_BADARG;
+template <int MODE, int TQ>
+static int launch_pam_tq(const PamArgs &a, int N, hipStream_t s, size_t lds) {
     static size_t attr = 0;
     if (lds > attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pam_attend_kernel<MODE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pam_attend_kernel<MODE, TQ>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr = lds;
     }
-    dim3 grid((a.W + kPamTQ - 1) / kPamTQ, a.H, N);
-    hipLaunchKernelGGL((pam_attend_kernel<MODE>), grid, dim3(256), lds, s, a);
+    dim3 grid((a.W + TQ - 1) / TQ, a.H, N);
+    hipLaunchKernelGGL((pam_attend_kernel<MODE, TQ>), grid, dim3(256), lds, s, a);
     CT_CHECK_LAUNCH();
     return CT_OK;
+}
+
+static int pam_tq(int W) {   // queries per workgroup such that S (TQ x W) + Q tile + K chunk fit the 160 KiB LDS
+    const size_t lds32 = ((size_t)32 * (W | 1) + kPamC * 32 + kPamC * kPamKC) * sizeof(float);
+    const size_t lds16 = ((size_t)16 * (W | 1) + kPamC * 16 + kPamC * kPamKC) * sizeof(float);
+    if (lds32 <= 160 * 1024) return 32;
+    if (lds16 <= 160 * 1024) return 16;
+    return 0;
+}
+
+template <int MODE>
+static int launch_pam(const PamArgs &a, int N, hipStream_t s) {
+    static_assert(96 * (kPamJC + 1) <= kPamC * kPamKC, "V chunk must fit the K chunk region");
+    if (a.C != kPamC) return CT_E_BADARG;
+    const int tq = pam_tq(a.W);
+    if (tq == 0) return CT_E_BADARG;   // W > 1982: needs the streaming (online-softmax) variant
+    const size_t lds = ((size_t)tq * (a.W | 1) + kPamC * tq + kPamC * kPamKC) * sizeof(float);
+    return tq == 32 ? launch_pam_tq<MODE, 32>(a, N, s, lds) : launch_pam_tq<MODE, 16>(a, N, s, lds);
 }
 
 }  // namespace ct
@@ -687,7 +701,9 @@ int ct_conv2d_prof_f32(const float *in, const float *wp, const float *bias, cons
 
 size_t ct_pam_workspace_bytes(int n, int h, int w) {
     if (n < 0 || h < 0 || w < 0) return 0;
-    return (size_t)n * h * ((w + ct::kPamTQ - 1) / ct::kPamTQ) * w * sizeof(float);
+    const int tq = ct::pam_tq(w);
+    if (tq == 0) return 0;
+    return (size_t)n * h * ((w + tq - 1) / tq) * w * sizeof(float);
 }
 
 int ct_pam_attend_f32(const float *q, const float *k, const float *v, const float *rgb, float *out_v, float *out_rgb,
@@ -712,7 +728,7 @@ int ct_pam_valid_f32(const float *q, const float *k, float *valid, float *colsum
     a.C = c; a.CV = 0; a.H = h; a.W = w;
     int rc = ct::launch_pam<1>(a, n, (hipStream_t)stream);
     if (rc) return rc;
-    const int tiles = (w + ct::kPamTQ - 1) / ct::kPamTQ;
+    const int tiles = (w + ct::pam_tq(w) - 1) / ct::pam_tq(w);
     hipLaunchKernelGGL(ct::pam_valid_kernel, dim3((w + 255) / 256, h, n), dim3(256), 0, (hipStream_t)stream,
                        (const float *)ws, tiles, h, w, valid, colsum);
     CT_CHECK_LAUNCH();

@@ -101,3 +101,29 @@ def test_forward_vs_oracle_odd_size_and_load_state_dict():
         m.transfer[-1].bias.add_(0.25)
     p2 = m.forward_parts(left.cuda(), right.cuda())
     close((p2["pre_clamp"] - p["pre_clamp"]).cpu().numpy(), 0.25, "bias update visible", atol=1e-6)
+
+
+@pytest.mark.parametrize("h,w", [(3, 70), (2, 512), (2, 1030), (2, 1920)])
+def test_pam_kernels_vs_torch_reference(h, w):
+    """ct_pam_attend_f32 / ct_pam_valid_f32 alone, including the 16-query variant used for W > 992 (1080p)
+    and a width that is no multiple of 4 (scalar staging path)."""
+    import ct_hip
+    gen = torch.Generator().manual_seed(w)
+    q = torch.randn(1, 64, h, w, generator=gen) * 2
+    k = torch.randn(1, 64, h, w, generator=gen) * 2
+    v = torch.randn(1, 64, h, w, generator=gen)
+    rgb = torch.rand(1, 3, h, w, generator=gen)
+    cost = torch.matmul(q.double().permute(0, 2, 3, 1), k.double().permute(0, 2, 1, 3)) / 64
+    att = torch.softmax(cost, dim=-1)
+    want_v = torch.matmul(att, v.double().permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+    want_rgb = torch.matmul(att, rgb.double().permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+    out_v, out_rgb, got_att = ct_hip.pam_attend(q.cuda(), k.cuda(), v.cuda(), rgb.cuda(), want_att=(w <= 1030))
+    close(out_v.cpu().numpy(), want_v.numpy(), "warp(v)", atol=2e-5)
+    close(out_rgb.cpu().numpy(), want_rgb.numpy(), "warp(rgb)", atol=2e-5)
+    if got_att is not None:
+        close(got_att.cpu().numpy(), att.numpy(), "att", atol=1e-6)
+    valid, colsum, _ = ct_hip.pam_valid(q.cuda(), k.cuda())
+    want_cs = att.sum(dim=-2)
+    close(colsum[:, 0].cpu().numpy(), want_cs.numpy(), "colsum", atol=2e-5)
+    safe = (want_cs - 0.1).abs() > 1e-3
+    assert ((valid[:, 0].cpu() > 0.5)[safe] == (want_cs > 0.1)[safe]).all()
