@@ -1,0 +1,781 @@
+// gmflow.hip -- building blocks of the GMFlow / UniMatch matcher forward (DMSCT's matcher) on gfx950.
+//
+// Replaces the ATen op sequences of the reference's unimatch/*.py for the one configuration DMSCT uses
+// (methods/dmsct.py:85-94).  float32 in, float32 accumulate everywhere (exact-f32 MFMA for
+// the contractions), so parity against the float32 reference is at rounding level.
+//
+//   conv_generic_kernel      Conv2d, any kernel / stride / channel count (backbone.py, reg_refine.py)        NCHW
+//   inorm_*                  InstanceNorm2d (affine=False, eps 1e-5) [+ReLU] [+skip, ReLU] (backbone.py:34-39) NCHW
+//   linear_tokens_kernel     nn.Linear on [tokens][C] (transformer.py:26-41, attention.py:181-182)            NLC
+//   layernorm_tokens_kernel  LayerNorm(128) [+ residual]  (transformer.py:32,43,139-147)                        NLC
+//   attention_tokens_kernel  softmax(Q K^T / sqrt(C) [+ shift mask]) V, streaming (online softmax), V = 128
+//                            channels (swin window attention, attention.py:48-107) or 2 channels (global
+//                            correlation -> expected coordinates, matching.py:10-39; flow propagation,
+//                            attention.py:199-216)                                                              NLC
+//   local_corr_softmax / local_corr_flow / local_attn_prop    matching.py:42-126, attention.py:220-256
+//   convex_upsample, bilinear_resize, flow_warp, fb_check, gru ops, elementwise   utils.py:137-155, geometry.py
+#include "ct_common.h"
+
+namespace ct {
+
+typedef float f32x16g __attribute__((ext_vector_type(16)));
+
+// =================================================================================================
+// Generic convolution: M = 64 output channels per workgroup, N = 4 rows x 32 columns of output pixels,
+// K = (kh*kw) taps x input channels staged through LDS in chunks.
+// =================================================================================================
+struct GConvArgs {
+    const float *in, *wp, *bias;   // wp: [kh*kw][cin_pairs][2][coutp], coutp = 64*ceil(cout/64); bias padded to coutp (or null)
+    float *out;
+    int cin, cout, coutp, H, W, Ho, Wo, KH, KW, stride, padH, padW;
+    long long in_bstride, out_bstride;
+    int act;      // 0 none, 1 LeakyReLU(0.01), 2 ReLU, 3 sigmoid, 4 tanh
+    int cchunk;   // input channels staged per LDS pass (even)
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case 1: return v > 0.f ? v : 0.01f * v;
+        case 2: return v > 0.f ? v : 0.f;
+        case 3: return 1.0f / (1.0f + expf(-v));
+        case 4: return tanhf(v);
+        default: return v;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void conv_generic_kernel(GConvArgs a, int tiles_x, int tiles_y) {
+    extern __shared__ float tin[];     // [cchunk][TR][TC]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, hl = lane >> 5;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int n = blockIdx.z, mt0 = blockIdx.y * 64;           // first output channel of this workgroup
+    const int TR = 3 * a.stride + a.KH, TC = 31 * a.stride + a.KW, CS = TR * TC;
+    const int oy0 = ty * 4, ox0 = tx * 32;
+    const int iy0 = oy0 * a.stride - a.padH, ix0 = ox0 * a.stride - a.padW;
+    const size_t iplane = (size_t)a.H * a.W, oplane = (size_t)a.Ho * a.Wo;
+    const float *in = a.in + (size_t)n * a.in_bstride;
+    const int cin_pairs = (a.cin + 1) >> 1;
+    f32x16g acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+    for (int c0 = 0; c0 < a.cin; c0 += a.cchunk) {
+        const int cc = (a.cin - c0) < a.cchunk ? (a.cin - c0) : a.cchunk;
+        const int ccp = (cc + 1) >> 1;
+        __syncthreads();
+        for (int idx = tid; idx < 2 * ccp * CS; idx += 256) {
+            const int c = idx / CS, rem = idx - c * CS;
+            const int yy = rem / TC, xx = rem - yy * TC;
+            const int gy = iy0 + yy, gx = ix0 + xx;
+            float v = 0.f;
+            if (c < cc && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = in[(size_t)(c0 + c) * iplane + (size_t)gy * a.W + gx];
+            tin[idx] = v;
+        }
+        __syncthreads();
+        for (int tap = 0; tap < a.KH * a.KW; ++tap) {
+            const int ky = tap / a.KW, kx = tap - ky * a.KW;
+            const float *brow = tin + hl * CS + (wave * a.stride + ky) * TC + nl * a.stride + kx;
+            const float *wrow = a.wp + ((size_t)tap * cin_pairs + (c0 >> 1)) * 2 * a.coutp + hl * a.coutp + mt0 + nl;
+            for (int p = 0; p < ccp; ++p) {
+                const float b = brow[p * 2 * CS];
+                const float w0 = wrow[(size_t)p * 2 * a.coutp], w1 = wrow[(size_t)p * 2 * a.coutp + 32];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, b, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, b, acc[1], 0, 0, 0);
+            }
+        }
+    }
+    const int oy = oy0 + wave, ox = ox0 + nl;
+    if (oy < a.Ho && ox < a.Wo) {
+        float *out = a.out + (size_t)n * a.out_bstride + (size_t)oy * a.Wo + ox;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = mt0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+                if (co < a.cout) {
+                    float v = acc[m][r] + (a.bias ? a.bias[co] : 0.f);
+                    out[(size_t)co * oplane] = apply_act(v, a.act);
+                }
+            }
+    }
+}
+
+// =================================================================================================
+// InstanceNorm2d (affine=False, biased variance, eps): one workgroup per (n, c) plane, two passes.
+//   mode 0: y = IN(x)          mode 1: y = relu(IN(x))          mode 2: y = relu(skip + relu(IN(x)))   (backbone.py:34-39)
+//   mode 3: y = relu(IN(x) + skip')  is not needed: the downsample branch is normalised by its own launch.
+// =================================================================================================
+__global__ __launch_bounds__(256) void inorm_kernel(const float *__restrict__ x, const float *__restrict__ skip,
+                                                    float *__restrict__ y, int plane, float eps, int mode) {
+    __shared__ double red[8];
+    const size_t base = (size_t)blockIdx.x * plane;
+    double s = 0.0, ss = 0.0;
+    for (int i = threadIdx.x; i < plane; i += 256) {
+        const double v = x[base + i];
+        s += v;
+        ss += v * v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off, 64);
+        ss += __shfl_down(ss, off, 64);
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { red[wid] = s; red[4 + wid] = ss; }
+    __syncthreads();
+    const double ts = red[0] + red[1] + red[2] + red[3], tss = red[4] + red[5] + red[6] + red[7];
+    const double mean = ts / plane;
+    double var = tss / plane - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float fm = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int i = threadIdx.x; i < plane; i += 256) {
+        float v = (x[base + i] - fm) * rstd;
+        if (mode >= 1) v = v > 0.f ? v : 0.f;
+        if (mode == 2) { v += skip[base + i]; v = v > 0.f ? v : 0.f; }
+        y[base + i] = v;
+    }
+}
+
+// =================================================================================================
+// Elementwise helpers
+//   op 0: y = a + b              op 1: y = a * b                  op 2: y = (1 - z) * h + z * q   (a=z, b=h, c=q)
+//   op 3: y = (a / 255 - mean[c]) / std[c]   (normalize_img, utils.py:26-34; a: [N,3,H,W], plane given)
+//   op 4: y = a * s0             op 5: tanh(a) for channels < split, relu(a) otherwise (refine_proj chunk, unimatch.py:320-323)
+// =================================================================================================
+__global__ void eltwise_kernel(const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ c,
+                               float *__restrict__ y, long long n, int op, int plane, int chans, int split, float s0) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v;
+    switch (op) {
+        case 0: v = a[i] + b[i]; break;
+        case 1: v = a[i] * b[i]; break;
+        case 2: v = (1.0f - a[i]) * b[i] + a[i] * c[i]; break;
+        case 3: {
+            const int ch = (int)((i / plane) % 3);
+            const float mean = ch == 0 ? 0.485f : (ch == 1 ? 0.456f : 0.406f);
+            const float sd = ch == 0 ? 0.229f : (ch == 1 ? 0.224f : 0.225f);
+            v = (a[i] / 255.0f - mean) / sd;
+            break;
+        }
+        case 4: v = a[i] * s0; break;
+        default: {
+            const int ch = (int)((i / plane) % chans);
+            v = ch < split ? tanhf(a[i]) : (a[i] > 0.f ? a[i] : 0.f);
+        }
+    }
+    y[i] = v;
+}
+
+// =================================================================================================
+// nn.Linear on channels-last tokens: out[t][n] = act( sum_k x[t][k] W[n][k] + bias[n] )
+// One wave owns 32 tokens x 128 output features; A (tokens) and B (weight rows, PyTorch layout [N][K]) are read with
+// 16-byte loads straight into registers: the contraction index of the two lane halves is split as
+// k = hl*K/2 + p (any order is a valid dot product), so a lane needs K/2 CONSECUTIVE channels of its row.
+// K % 16 == 0 (128, 256, 1024 here).  grid = (ceil(T/32/4), ceil(N/128)); block = 4 waves = 128 tokens.
+// =================================================================================================
+__global__ __launch_bounds__(256) void linear_tokens_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                            const float *__restrict__ bias, float *__restrict__ out,
+                                                            long long T, int K, int N, int act /*0 none, 6 gelu*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nl = lane & 31, hl = lane >> 5;
+    const long long t0 = ((long long)blockIdx.x * 4 + wave) * 32;
+    const int n0 = blockIdx.y * 128;
+    if (t0 >= T) return;
+    const int kh = K >> 1;
+    const long long trow = t0 + nl;
+    const float *xa = x + (trow < T ? trow : T - 1) * K + hl * kh;
+    f32x16g acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int k0 = 0; k0 < kh; k0 += 8) {
+        const float4 a0 = *reinterpret_cast<const float4 *>(xa + k0), a1 = *reinterpret_cast<const float4 *>(xa + k0 + 4);
+        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nrow = n0 + j * 32 + nl;
+            const float *wb = w + (size_t)(nrow < N ? nrow : N - 1) * K + hl * kh + k0;
+            const float4 b0 = *reinterpret_cast<const float4 *>(wb), b1 = *reinterpret_cast<const float4 *>(wb + 4);
+            const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int p = 0; p < 8; ++p) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], bv[p], acc[j], 0, 0, 0);
+        }
+    }
+    // D[token i][feature j]: lane = feature, registers = tokens (r&3)+8(r>>2)+4hl
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int nf = n0 + j * 32 + nl;
+        if (nf < N) {
+            const float bb = bias ? bias[nf] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long t = t0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+                if (t < T) {
+                    float v = acc[j][r] + bb;
+                    if (act == 6) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));   // exact GELU (nn.GELU default)
+                    out[t * N + nf] = v;
+                }
+            }
+        }
+    }
+}
+
+// LayerNorm over the last dim (C = 128, eps 1e-5, affine) of [T][128], optional residual: out = res + LN(x).
+// One wave per token (2 channels per lane).
+__global__ __launch_bounds__(256) void layernorm_tokens_kernel(const float *__restrict__ x, const float *__restrict__ g,
+                                                               const float *__restrict__ b, const float *__restrict__ res,
+                                                               float *__restrict__ out, long long T) {
+    const int lane = threadIdx.x & 63;
+    const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    const float2 v = *reinterpret_cast<const float2 *>(x + t * 128 + 2 * lane);
+    float s = v.x + v.y;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float mean = s * (1.0f / 128.0f);
+    const float dx = v.x - mean, dy = v.y - mean;
+    float ss = dx * dx + dy * dy;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    const float rstd = 1.0f / sqrtf(ss * (1.0f / 128.0f) + 1e-5f);
+    float o0 = dx * rstd * g[2 * lane] + b[2 * lane], o1 = dy * rstd * g[2 * lane + 1] + b[2 * lane + 1];
+    if (res) { o0 += res[t * 128 + 2 * lane]; o1 += res[t * 128 + 2 * lane + 1]; }
+    *reinterpret_cast<float2 *>(out + t * 128 + 2 * lane) = make_float2(o0, o1);
+}
+
+// =================================================================================================
+// Streaming single-head attention on channels-last tokens (C = 128):
+//   out[b][i][:] = sum_j softmax_j( q[b][i].k[b][j] / sqrt(C) + mask(i,j) ) v[b][j][:]
+// One wave = 32 queries; keys are visited 32 at a time with an online softmax.  The score tile is computed
+// TRANSPOSED (M = keys, N = queries), so a lane owns ONE query column: its running max / sum / rescale are
+// per-lane scalars and the accumulator (also query-on-lane) rescales without any cross-lane traffic.
+//   CV == 128: P.V on MFMA (M = value channels, N = queries, K = keys, P taken from the score registers)
+//   CV == 2  : the two value channels (coordinates / flow) are accumulated by the VALU
+//   region != null: additive -100 where region[i] != region[j] (shifted-window mask, utils.py:87-111)
+// q/k/v rows are fetched with 16-byte loads (a lane needs C/2 consecutive channels of one token row).
+// grid = (ceil(L/128), B); block = 4 waves.
+// =================================================================================================
+template <int CV>
+__global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                               const float *__restrict__ v, const int *__restrict__ region,
+                                                               float *__restrict__ out, int L, float scale) {
+    constexpr int C = 128;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nl = lane & 31, hl = lane >> 5;
+    const int b = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    if (q0 >= L) return;
+    const size_t tb = (size_t)b * L;
+    const int qi = q0 + nl;
+    const bool qlive = qi < L;
+    // B operand of S^T = K Q^T : lane (query nl, half hl) holds q[query][hl*64 + p], p < 64
+    float qb[64];
+    {
+        const float *qp = q + (tb + (qlive ? qi : L - 1)) * C + hl * 64;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float4 t = *reinterpret_cast<const float4 *>(qp + 4 * i);
+            qb[4 * i] = t.x * scale; qb[4 * i + 1] = t.y * scale; qb[4 * i + 2] = t.z * scale; qb[4 * i + 3] = t.w * scale;
+        }
+    }
+    const int qreg = region ? region[tb + (qlive ? qi : L - 1)] : 0;
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16g o[CV == 128 ? 4 : 1];
+    float o2x = 0.f, o2y = 0.f;
+    if (CV == 128) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
+    }
+    for (int j0 = 0; j0 < L; j0 += 32) {
+        // ---- S^T tile: A = K rows (key nl), B = Q ----
+        const int kj = j0 + nl;
+        const float *kp = k + (tb + (kj < L ? kj : L - 1)) * C + hl * 64;
+        f32x16g s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float4 t = *reinterpret_cast<const float4 *>(kp + 4 * i);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(t.x, qb[4 * i], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(t.y, qb[4 * i + 1], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(t.z, qb[4 * i + 2], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(t.w, qb[4 * i + 3], s, 0, 0, 0);
+        }
+        // lane: query nl; s[r] = score of key j0 + (r&3)+8(r>>2)+4hl
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+            float sv = s[r];
+            if (region) sv += (region[tb + (key < L ? key : L - 1)] != qreg) ? -100.0f : 0.0f;
+            sv = key < L ? sv : -INFINITY;
+            s[r] = sv;
+            mx = fmaxf(mx, sv);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));          // the other half of the keys of this query
+        const float m_new = fmaxf(m_run, mx);
+        const float corr = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = (s[r] == -INFINITY) ? 0.f : expf(s[r] - m_new);
+            s[r] = p;
+            psum += p;
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * corr + psum;
+        m_run = m_new;
+        if (CV == 128) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[j][r] *= corr;
+            // O^T[c][query] += sum_key V[key][c] P[key][query]: k-step r pairs the keys held by the two lane halves
+            // in register r (keys kk and kk+4); A = V[key][channel nl of each 32-channel tile]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+                const float *vp = v + (tb + (key < L ? key : L - 1)) * C + nl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * j], s[r], o[j], 0, 0, 0);
+            }
+        } else {
+            float ax = 0.f, ay = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+                const float2 vv = *reinterpret_cast<const float2 *>(v + (tb + (key < L ? key : L - 1)) * 2);
+                ax += s[r] * vv.x;
+                ay += s[r] * vv.y;
+            }
+            ax += __shfl_xor(ax, 32, 64);
+            ay += __shfl_xor(ay, 32, 64);
+            o2x = o2x * corr + ax;
+            o2y = o2y * corr + ay;
+        }
+    }
+    const float inv = 1.0f / l_run;
+    if (CV == 128) {
+        // O^T[c][query]: lane = query nl, registers = channels (r&3)+8(r>>2)+4hl of tile j
+        if (qlive) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) out[(tb + qi) * C + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl] = o[j][r] * inv;
+        }
+    } else {
+        if (qlive && hl == 0) *reinterpret_cast<float2 *>(out + (tb + qi) * 2) = make_float2(o2x * inv, o2y * inv);
+    }
+}
+
+// =================================================================================================
+// Local correlation kernels on channels-last features f0, f1: [B][H*W][128]
+// =================================================================================================
+// matching.py:42-86: softmax over the (2R+1)^2 integer neighbours (out-of-image taps masked to -1e9), expected
+// coordinate minus own coordinate -> flow [B][2][H][W].  One wave per pixel, lanes over taps.
+__global__ __launch_bounds__(256) void local_corr_softmax_kernel(const float *__restrict__ f0, const float *__restrict__ f1,
+                                                                 float *__restrict__ flow, int H, int W, int R, float scale) {
+    constexpr int C = 128;
+    const int lane = threadIdx.x & 63;
+    const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    if (pix >= (long long)H * W) return;
+    const int y = (int)(pix / W), x = (int)(pix % W);
+    const int D = 2 * R + 1, NT = D * D;
+    const float *a = f0 + ((size_t)b * H * W + pix) * C;
+    float mx = -INFINITY;
+    float sc[2];
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        const int t = lane + rep * 64;
+        float s = -INFINITY;
+        if (t < NT) {
+            const int dy = t / D - R, dx = t % D - R;
+            const int yy = y + dy, xx = x + dx;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                const float *bp = f1 + ((size_t)b * H * W + (size_t)yy * W + xx) * C;
+                float acc = 0.f;
+                for (int c = 0; c < C; c += 4) {
+                    const float4 u = *reinterpret_cast<const float4 *>(a + c), w4 = *reinterpret_cast<const float4 *>(bp + c);
+                    acc += u.x * w4.x + u.y * w4.y + u.z * w4.z + u.w * w4.w;
+                }
+                s = acc * scale;
+            } else {
+                s = -1e9f;                                  // matching.py:76
+            }
+        }
+        sc[rep] = s;
+        mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    float sum = 0.f, ex = 0.f, ey = 0.f;
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        const int t = lane + rep * 64;
+        if (t < NT) {
+            const float p = expf(sc[rep] - mx);
+            sum += p;
+            ex += p * (float)(x + t % D - R);
+            ey += p * (float)(y + t / D - R);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sum += __shfl_xor(sum, off, 64);
+        ex += __shfl_xor(ex, off, 64);
+        ey += __shfl_xor(ey, off, 64);
+    }
+    if (lane == 0) {
+        flow[((size_t)b * 2 + 0) * H * W + pix] = ex / sum - (float)x;
+        flow[((size_t)b * 2 + 1) * H * W + pix] = ey / sum - (float)y;
+    }
+}
+
+// matching.py:89-126: corr[b][t][y][x] = f0(y,x) . bilinear(f1, (x,y) + window[t] + flow) / sqrt(C), zeros padding,
+// align_corners=True (grid_sample of exactly representable pixel coordinates).  One wave per pixel, lanes over taps.
+__global__ __launch_bounds__(256) void local_corr_flow_kernel(const float *__restrict__ f0, const float *__restrict__ f1,
+                                                              const float *__restrict__ flow, float *__restrict__ corr, int H,
+                                                              int W, int R, float scale) {
+    constexpr int C = 128;
+    const int lane = threadIdx.x & 63;
+    const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    if (pix >= (long long)H * W) return;
+    const int y = (int)(pix / W), x = (int)(pix % W);
+    const int D = 2 * R + 1, NT = D * D;
+    const size_t hw = (size_t)H * W;
+    const float fx = flow[((size_t)b * 2 + 0) * hw + pix], fy = flow[((size_t)b * 2 + 1) * hw + pix];
+    const float *a = f0 + ((size_t)b * hw + pix) * C;
+    for (int t = lane; t < NT; t += 64) {
+        // the reference normalises to [-1,1] and grid_sample maps back: ((g + 1) / 2) * (size - 1)
+        const float sx = (float)x + (float)(t % D - R) + fx, sy = (float)y + (float)(t / D - R) + fy;
+        const float cx = (W - 1) * 0.5f, cy = (H - 1) * 0.5f;
+        const float gx = (sx - cx) / cx, gy = (sy - cy) / cy;
+        const float px = ((gx + 1.0f) * 0.5f) * (float)(W - 1), py = ((gy + 1.0f) * 0.5f) * (float)(H - 1);
+        const float x0f = floorf(px), y0f = floorf(py);
+        const int x0 = (int)x0f, y0 = (int)y0f;
+        const float wx1 = px - x0f, wy1 = py - y0f, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+        float acc = 0.f;
+#pragma unroll
+        for (int corner = 0; corner < 4; ++corner) {
+            const int xx = x0 + (corner & 1), yy = y0 + (corner >> 1);
+            const float wgt = ((corner & 1) ? wx1 : wx0) * ((corner >> 1) ? wy1 : wy0);
+            if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
+                const float *bp = f1 + ((size_t)b * hw + (size_t)yy * W + xx) * C;
+                float d = 0.f;
+                for (int c = 0; c < C; c += 4) {
+                    const float4 u = *reinterpret_cast<const float4 *>(a + c), w4 = *reinterpret_cast<const float4 *>(bp + c);
+                    d += u.x * w4.x + u.y * w4.y + u.z * w4.z + u.w * w4.w;
+                }
+                acc += wgt * d;
+            }
+        }
+        corr[((size_t)b * NT + t) * hw + pix] = acc * scale;
+    }
+}
+
+// attention.py:220-256: 3x3 (radius r) local window attention: q = q_proj(f) (tokens [B][HW][128]), kp = k_proj(f) (same
+// layout), value = flow [B][2][H][W]; zero padding of both keys and values (F.unfold).  One wave per pixel.
+__global__ __launch_bounds__(256) void local_attn_prop_kernel(const float *__restrict__ qf, const float *__restrict__ kf,
+                                                              const float *__restrict__ flow, float *__restrict__ out, int H,
+                                                              int W, int R, float scale) {
+    constexpr int C = 128;
+    const int lane = threadIdx.x & 63;
+    const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    if (pix >= (long long)H * W) return;
+    const int y = (int)(pix / W), x = (int)(pix % W);
+    const int D = 2 * R + 1, NT = D * D;
+    const size_t hw = (size_t)H * W;
+    const float *a = qf + ((size_t)b * hw + pix) * C;
+    float s = -INFINITY, vx = 0.f, vy = 0.f;
+    if (lane < NT) {
+        const int yy = y + lane / D - R, xx = x + lane % D - R;
+        s = 0.f;                                            // out-of-image key = zero vector (unfold padding) -> score 0
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            const float *bp = kf + ((size_t)b * hw + (size_t)yy * W + xx) * C;
+            float acc = 0.f;
+            for (int c = 0; c < C; c += 4) {
+                const float4 u = *reinterpret_cast<const float4 *>(a + c), w4 = *reinterpret_cast<const float4 *>(bp + c);
+                acc += u.x * w4.x + u.y * w4.y + u.z * w4.z + u.w * w4.w;
+            }
+            s = acc * scale;
+            vx = flow[((size_t)b * 2 + 0) * hw + (size_t)yy * W + xx];
+            vy = flow[((size_t)b * 2 + 1) * hw + (size_t)yy * W + xx];
+        }
+    }
+    float mx = s;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    float p = lane < NT ? expf(s - mx) : 0.f;
+    float sum = p, ox = p * vx, oy = p * vy;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sum += __shfl_xor(sum, off, 64);
+        ox += __shfl_xor(ox, off, 64);
+        oy += __shfl_xor(oy, off, 64);
+    }
+    if (lane == 0) {
+        out[((size_t)b * 2 + 0) * hw + pix] = ox / sum;
+        out[((size_t)b * 2 + 1) * hw + pix] = oy / sum;
+    }
+}
+
+// =================================================================================================
+// Sampling / resampling (NCHW)
+// =================================================================================================
+// F.interpolate(mode='bilinear', align_corners=True) to (Ho, Wo), times `mul[c]` (mul0 for channel 0, mul1 otherwise)
+__global__ void bilinear_resize_kernel(const float *__restrict__ in, float *__restrict__ out, int NC, int C, int H, int W, int Ho,
+                                       int Wo, float mul0, float mul1) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)NC * Ho * Wo;
+    if (i >= total) return;
+    const int xo = (int)(i % Wo), yo = (int)((i / Wo) % Ho);
+    const long long nc = i / ((long long)Ho * Wo);
+    const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const float fy = sy * yo, fx = sx * xo;
+    int y0 = (int)fy, x0 = (int)fx;
+    y0 = y0 < H - 1 ? y0 : H - 1; x0 = x0 < W - 1 ? x0 : W - 1;
+    const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
+    const float ly = fy - y0, lx = fx - x0;
+    const float *p = in + nc * (long long)H * W;
+    const float v = (1.f - ly) * ((1.f - lx) * p[(size_t)y0 * W + x0] + lx * p[(size_t)y0 * W + x1]) +
+                    ly * ((1.f - lx) * p[(size_t)y1 * W + x0] + lx * p[(size_t)y1 * W + x1]);
+    out[i] = v * (((int)(nc % C) == 0) ? mul0 : mul1);
+}
+
+// geometry.py:43-75: out = grid_sample(img, (x + flow_x, y + flow_y)), bilinear, zeros padding, align_corners=True
+__global__ void flow_warp_kernel(const float *__restrict__ img, const float *__restrict__ flow, float *__restrict__ out, int N, int C,
+                                 int H, int W) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long hw = (long long)H * W;
+    if (i >= (long long)N * hw) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H), n = (int)(i / hw);
+    const float sx = (float)x + flow[((size_t)n * 2 + 0) * hw + (size_t)y * W + x];
+    const float sy = (float)y + flow[((size_t)n * 2 + 1) * hw + (size_t)y * W + x];
+    // bilinear_sample normalises (2 x / (w-1) - 1) and grid_sample maps back ((g + 1) / 2 * (w - 1))
+    const float gx = 2.0f * sx / (float)(W - 1) - 1.0f, gy = 2.0f * sy / (float)(H - 1) - 1.0f;
+    const float px = ((gx + 1.0f) * 0.5f) * (float)(W - 1), py = ((gy + 1.0f) * 0.5f) * (float)(H - 1);
+    const float x0f = floorf(px), y0f = floorf(py);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float wx1 = px - x0f, wy1 = py - y0f, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x0 + 1 >= 0 && x0 + 1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y0 + 1 >= 0 && y0 + 1 < H;
+    for (int c = 0; c < C; ++c) {
+        const float *p = img + ((size_t)n * C + c) * hw;
+        float v = 0.f;
+        if (vy0 && vx0) v += wy0 * wx0 * p[(size_t)y0 * W + x0];
+        if (vy0 && vx1) v += wy0 * wx1 * p[(size_t)y0 * W + x0 + 1];
+        if (vy1 && vx0) v += wy1 * wx0 * p[(size_t)(y0 + 1) * W + x0];
+        if (vy1 && vx1) v += wy1 * wx1 * p[(size_t)(y0 + 1) * W + x0 + 1];
+        out[((size_t)n * C + c) * hw + (size_t)y * W + x] = v;
+    }
+}
+
+// utils.py:137-155: convex upsampling by `f` (mask [B][9*f*f][H][W], flow [B][2][H][W] -> [B][2][fH][fW])
+__global__ void convex_upsample_kernel(const float *__restrict__ flow, const float *__restrict__ mask, float *__restrict__ out, int B,
+                                       int H, int W, int f) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Ho = H * f, Wo = W * f;
+    if (i >= (long long)B * Ho * Wo) return;
+    const int xo = (int)(i % Wo), yo = (int)((i / Wo) % Ho), b = (int)(i / ((long long)Ho * Wo));
+    const int x = xo / f, y = yo / f, kx = xo % f, ky = yo % f;
+    const size_t hw = (size_t)H * W;
+    float m[9], mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        m[t] = mask[((size_t)b * 9 * f * f + (size_t)t * f * f + ky * f + kx) * hw + (size_t)y * W + x];
+        mx = fmaxf(mx, m[t]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { m[t] = expf(m[t] - mx); sum += m[t]; }
+    float ox = 0.f, oy = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            const float p = m[t] / sum;
+            ox += p * (float)f * flow[((size_t)b * 2 + 0) * hw + (size_t)yy * W + xx];
+            oy += p * (float)f * flow[((size_t)b * 2 + 1) * hw + (size_t)yy * W + xx];
+        }
+    }
+    out[((size_t)b * 2 + 0) * Ho * Wo + (size_t)yo * Wo + xo] = ox;
+    out[((size_t)b * 2 + 1) * Ho * Wo + (size_t)yo * Wo + xo] = oy;
+}
+
+// geometry.py:78-99 given the two warped flows: occ = (|a + wa| > alpha (|fwd| + |bwd|) + beta) as 0/1
+__global__ void fb_check_kernel(const float *__restrict__ fwd, const float *__restrict__ bwd, const float *__restrict__ wbwd,
+                                const float *__restrict__ wfwd, float *__restrict__ focc, float *__restrict__ bocc, int B, int H, int W,
+                                float alpha, float beta) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long hw = (long long)H * W;
+    if (i >= (long long)B * hw) return;
+    const long long b = i / hw, p = i % hw;
+    const size_t i0 = (size_t)(b * 2) * hw + p, i1 = i0 + hw;
+    const float mag = sqrtf(fwd[i0] * fwd[i0] + fwd[i1] * fwd[i1]) + sqrtf(bwd[i0] * bwd[i0] + bwd[i1] * bwd[i1]);
+    const float dfx = fwd[i0] + wbwd[i0], dfy = fwd[i1] + wbwd[i1], dbx = bwd[i0] + wfwd[i0], dby = bwd[i1] + wfwd[i1];
+    const float thr = alpha * mag + beta;
+    focc[i] = sqrtf(dfx * dfx + dfy * dfy) > thr ? 1.0f : 0.0f;
+    bocc[i] = sqrtf(dbx * dbx + dby * dby) > thr ? 1.0f : 0.0f;
+}
+
+}  // namespace ct
+
+// -------------------------------------------------------------------------------------------------
+// C ABI (include/ct_hip.h)
+// -------------------------------------------------------------------------------------------------
+extern "C" {
+
+int ct_gconv2d_f32(const float *in, const float *wp, const float *bias, float *out, int n, int cin, int cout, int h, int w,
+                   int kh, int kw, int stride, int pad_h, int pad_w, long long in_bstride, long long out_bstride, int act,
+                   void *stream) {
+    if (!in || !wp || !out || n < 0 || cin < 1 || cout < 1 || h < 1 || w < 1 || kh < 1 || kw < 1 || stride < 1) return CT_E_BADARG;
+    if (n == 0) return CT_OK;
+    ct::GConvArgs a;
+    a.in = in; a.wp = wp; a.bias = bias; a.out = out;
+    a.cin = cin; a.cout = cout; a.coutp = 64 * ((cout + 63) / 64);
+    a.H = h; a.W = w; a.KH = kh; a.KW = kw; a.stride = stride; a.padH = pad_h; a.padW = pad_w;
+    a.Ho = (h + 2 * pad_h - kh) / stride + 1; a.Wo = (w + 2 * pad_w - kw) / stride + 1;
+    if (a.Ho < 1 || a.Wo < 1) return CT_E_BADARG;
+    a.in_bstride = in_bstride; a.out_bstride = out_bstride; a.act = act;
+    const int TR = 3 * stride + kh, TC = 31 * stride + kw;
+    int cchunk = (48 * 1024) / (TR * TC * 4);
+    cchunk &= ~1;
+    if (cchunk > 32) cchunk = 32;
+    if (cchunk < 2) return CT_E_BADARG;
+    a.cchunk = cchunk;
+    const size_t lds = (size_t)cchunk * TR * TC * sizeof(float);
+    const int tiles_x = (a.Wo + 31) / 32, tiles_y = (a.Ho + 3) / 4;
+    dim3 grid(tiles_x * tiles_y, a.coutp / 64, n);
+    hipLaunchKernelGGL(ct::conv_generic_kernel, grid, dim3(256), lds, (hipStream_t)stream, a, tiles_x, tiles_y);
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+}
+
+int ct_instance_norm_f32(const float *x, const float *skip, float *y, int planes, int plane, float eps, int mode, void *stream) {
+    if (!x || !y || planes < 0 || plane < 1 || (mode == 2 && !skip)) return CT_E_BADARG;
+    if (planes == 0) return CT_OK;
+    hipLaunchKernelGGL(ct::inorm_kernel, dim3(planes), dim3(256), 0, (hipStream_t)stream, x, skip, y, plane, eps, mode);
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+}
+
+int ct_eltwise_f32(const float *a, const float *b, const float *c, float *y, long long n, int op, int plane, int chans, int split,
+                   float s0, void *stream) {
+    if (!a || !y || n < 0) return CT_E_BADARG;
+    if (n == 0) return CT_OK;
+    hipLaunchKernelGGL(ct::eltwise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, c, y, n, op,
+                       plane > 0 ? plane : 1, chans > 0 ? chans : 1, split, s0);
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+}
+
+int ct_linear_tokens_f32(const float *x, const float *w, const float *bias, float *out, long long tokens, int k, int n, int act,
+                         void *stream) {
+    if (!x || !w || !out || tokens < 0 || k < 16 || (k % 16) || n < 1) return CT_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) return CT_E_ALIGN;
+    if (tokens == 0) return CT_OK;
+    dim3 grid((unsigned)((tokens + 127) / 128), (n + 127) / 128);
+    hipLaunchKernelGGL(ct::linear_tokens_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, out, tokens, k, n, act);
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+}
+
+int ct_layernorm128_f32(const float *x, const float *gamma, const float *beta, const float *residual, float *out, long long tokens,
+                        void *stream) {
+    if (!x || !gamma || !beta || !out || tokens < 0) return CT_E_BADARG;
+    if (tokens == 0) return CT_OK;
+    hipLaunchKernelGGL(ct::layernorm_tokens_kernel, dim3((unsigned)((tokens + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma,
+                       beta, residual, out, tokens);
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+}
+
+int ct_attention_tokens_f32(const float *q, const float *k, const float *v, const int *region, float *out, int batch, int len, int cv,
+                            float scale, void *stream) {
+    if (!q || !k || !v || !out || batch < 0 || len < 1 || (cv != 2 && cv != 128)) return CT_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k)) & 15) return CT_E_ALIGN;
+    if (batch == 0) return CT_OK;
+    dim3 grid((len + 127) / 128, batch);
+    if (cv == 128) hipLaunchKernelGGL((ct::attention_tokens_kernel<128>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, region, out, len, scale);
+    else hipLaunchKernelGGL((ct::attention_tokens_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, region, out, len, scale);
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+}
+
+int ct_local_corr_softmax_f32(const float *f0, const float *f1, float *flow, int batch, int h, int w, int radius, void *stream) {
+    if (!f0 || !f1 || !flow || batch < 0 || h < 1 || w < 1 || radius < 0 || (2 * radius + 1) * (2 * radius + 1) > 128) return CT_E_BADARG;
+    if (batch == 0) return CT_OK;
+    dim3 grid((unsigned)(((long long)h * w + 3) / 4), batch);
+    hipLaunchKernelGGL(ct::local_corr_softmax_kernel, grid, dim3(256), 0, (hipStream_t)stream, f0, f1, flow, h, w, radius,
+                       1.0f / sqrtf(128.0f));
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+}
+
+int ct_local_corr_flow_f32(const float *f0, const float *f1, const float *flow, float *corr, int batch, int h, int w, int radius,
+                           void *stream) {
+    if (!f0 || !f1 || !flow || !corr || batch < 0 || h < 2 || w < 2 || radius < 0) return CT_E_BADARG;
+    if (batch == 0) return CT_OK;
+    dim3 grid((unsigned)(((long long)h * w + 3) / 4), batch);
+    hipLaunchKernelGGL(ct::local_corr_flow_kernel, grid, dim3(256), 0, (hipStream_t)stream, f0, f1, flow, corr, h, w, radius,
+                       1.0f / sqrtf(128.0f));
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+}
+
+int ct_local_attn_prop_f32(const float *q, const float *k, const float *flow, float *out, int batch, int h, int w, int radius,
+                           void *stream) {
+    if (!q || !k || !flow || !out || batch < 0 || h < 1 || w < 1 || radius < 1 || (2 * radius + 1) * (2 * radius + 1) > 64) return CT_E_BADARG;
+    if (batch == 0) return CT_OK;
+    dim3 grid((unsigned)(((long long)h * w + 3) / 4), batch);
+    hipLaunchKernelGGL(ct::local_attn_prop_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, flow, out, h, w, radius,
+                       1.0f / sqrtf(128.0f));
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+}
+
+int ct_bilinear_resize_f32(const float *in, float *out, int n, int c, int h, int w, int ho, int wo, float mul0, float mul1, void *stream) {
+    if (!in || !out || n < 0 || c < 1 || h < 1 || w < 1 || ho < 1 || wo < 1) return CT_E_BADARG;
+    const long long total = (long long)n * c * ho * wo;
+    if (total == 0) return CT_OK;
+    hipLaunchKernelGGL(ct::bilinear_resize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, n * c,
+                       c, h, w, ho, wo, mul0, mul1);
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+}
+
+int ct_flow_warp_f32(const float *img, const float *flow, float *out, int n, int c, int h, int w, void *stream) {
+    if (!img || !flow || !out || n < 0 || c < 1 || h < 2 || w < 2) return CT_E_BADARG;
+    const long long total = (long long)n * h * w;
+    if (total == 0) return CT_OK;
+    hipLaunchKernelGGL(ct::flow_warp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, img, flow, out, n, c, h, w);
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+}
+
+int ct_convex_upsample_f32(const float *flow, const float *mask, float *out, int b, int h, int w, int factor, void *stream) {
+    if (!flow || !mask || !out || b < 0 || h < 1 || w < 1 || factor < 1) return CT_E_BADARG;
+    const long long total = (long long)b * h * factor * w * factor;
+    if (total == 0) return CT_OK;
+    hipLaunchKernelGGL(ct::convex_upsample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, flow, mask, out, b, h, w, factor);
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+}
+
+int ct_fb_check_f32(const float *fwd, const float *bwd, const float *warped_bwd, const float *warped_fwd, float *fwd_occ, float *bwd_occ,
+                    int b, int h, int w, float alpha, float beta, void *stream) {
+    if (!fwd || !bwd || !warped_bwd || !warped_fwd || !fwd_occ || !bwd_occ || b < 0) return CT_E_BADARG;
+    const long long total = (long long)b * h * w;
+    if (total == 0) return CT_OK;
+    hipLaunchKernelGGL(ct::fb_check_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fwd, bwd, warped_bwd, warped_fwd,
+                       fwd_occ, bwd_occ, b, h, w, alpha, beta);
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+}
+
+}  // extern "C"

@@ -338,3 +338,170 @@ def pam_valid(q, k, want_att=False):
     check(lib().ct_pam_valid_f32(_ptr(q), _ptr(k), _ptr(valid), _ptr(colsum), _ptr(att) if att is not None else _c_p(0),
                                  n, c, h, w, _ptr(ws), ws.numel(), _stream()))
     return valid, colsum, att
+
+
+# ------------------------------------------------------------------------------------------------
+# GMFlow building blocks (csrc/gmflow.hip)
+# ------------------------------------------------------------------------------------------------
+_c_f = ctypes.c_float
+SIGNATURES.update({
+    "ct_gconv2d_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 10 + [_c_ll, _c_ll, _c_int, _c_p]),
+    "ct_instance_norm_f32": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_f, _c_int, _c_p]),
+    "ct_eltwise_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_f, _c_p]),
+    "ct_linear_tokens_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p]),
+    "ct_layernorm128_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_p]),
+    "ct_attention_tokens_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_p]),
+    "ct_local_corr_softmax_f32": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    "ct_local_corr_flow_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    "ct_local_attn_prop_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    "ct_bilinear_resize_f32": (_c_int, [_c_p, _c_p] + [_c_int] * 6 + [_c_f, _c_f, _c_p]),
+    "ct_flow_warp_f32": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    "ct_convex_upsample_f32": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    "ct_fb_check_f32": (_c_int, [_c_p] * 6 + [_c_int, _c_int, _c_int, _c_f, _c_f, _c_p]),
+})
+
+ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_GELU = 0, 1, 2, 3, 4, 6
+
+
+def _f32c(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+            raise CtHipError("needs contiguous float32 CUDA tensors (no CPU path)")
+
+
+def _opt(t):
+    return _ptr(t) if t is not None else _c_p(0)
+
+
+def pack_gconv_weight(weight, bias):
+    """Conv2d parameters -> ct_gconv2d_f32 layout: wp[kh*kw][ceil(cin/2)][2][64*ceil(cout/64)], bias padded."""
+    cout, cin, kh, kw = weight.shape
+    coutp, cinp = 64 * ((cout + 63) // 64), 2 * ((cin + 1) // 2)
+    w = torch.zeros((coutp, cinp, kh, kw), dtype=torch.float32, device=weight.device)
+    w[:cout, :cin] = weight.detach().float()
+    wp = w.permute(2, 3, 1, 0).reshape(kh * kw, cinp // 2, 2, coutp).contiguous()
+    b = None
+    if bias is not None:
+        b = torch.zeros(coutp, dtype=torch.float32, device=weight.device)
+        b[:cout] = bias.detach().float()
+    return wp, b
+
+
+def gconv2d(x, wp, bias, cout, ksize, stride=1, padding=0, act=ACT_NONE, out=None):
+    kh, kw = (ksize, ksize) if isinstance(ksize, int) else ksize
+    ph, pw = (padding, padding) if isinstance(padding, int) else padding
+    n, cin, h, w = x.shape
+    ho, wo = (h + 2 * ph - kh) // stride + 1, (w + 2 * pw - kw) // stride + 1
+    if out is None:
+        out = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device)
+    check(lib().ct_gconv2d_f32(_ptr(x), _ptr(wp), _opt(bias), _ptr(out), n, cin, cout, h, w, kh, kw, stride, ph, pw,
+                               _nchw_bstride(x), _nchw_bstride(out), int(act), _stream()))
+    return out
+
+
+def instance_norm(x, mode=0, skip=None, eps=1e-5):
+    _f32c(x, skip)
+    n, c, h, w = x.shape
+    y = torch.empty_like(x)
+    check(lib().ct_instance_norm_f32(_ptr(x), _opt(skip), _ptr(y), n * c, h * w, eps, mode, _stream()))
+    return y
+
+
+def eltwise(op, a, b=None, c=None, plane=1, chans=1, split=0, s0=1.0):
+    _f32c(a, b, c)
+    y = torch.empty_like(a)
+    check(lib().ct_eltwise_f32(_ptr(a), _opt(b), _opt(c), _ptr(y), a.numel(), op, plane, chans, split, float(s0), _stream()))
+    return y
+
+
+def linear_tokens(x, weight, bias=None, act=ACT_NONE):
+    """x [..., K] channels-last tokens, weight [N, K] (PyTorch layout) -> [..., N]"""
+    _f32c(x, weight, bias)
+    k, n = x.shape[-1], weight.shape[0]
+    t = x.numel() // k
+    out = torch.empty(x.shape[:-1] + (n,), dtype=torch.float32, device=x.device)
+    check(lib().ct_linear_tokens_f32(_ptr(x), _ptr(weight), _opt(bias), _ptr(out), t, k, n, int(act), _stream()))
+    return out
+
+
+def layernorm128(x, gamma, beta, residual=None):
+    _f32c(x, gamma, beta, residual)
+    if x.shape[-1] != 128:
+        raise CtHipError("layernorm128: last dim must be 128")
+    out = torch.empty_like(x)
+    check(lib().ct_layernorm128_f32(_ptr(x), _ptr(gamma), _ptr(beta), _opt(residual), _ptr(out), x.numel() // 128, _stream()))
+    return out
+
+
+def attention_tokens(q, k, v, region=None, scale=None):
+    """q,k [B,L,128], v [B,L,128] or [B,L,2]; region int32 [B,L] or None -> [B,L,cv]"""
+    _f32c(q, k, v)
+    b, l, c = q.shape
+    cv = v.shape[-1]
+    if region is not None and (region.dtype != torch.int32 or not region.is_contiguous()):
+        raise CtHipError("region must be contiguous int32")
+    out = torch.empty((b, l, cv), dtype=torch.float32, device=q.device)
+    check(lib().ct_attention_tokens_f32(_ptr(q), _ptr(k), _ptr(v), _opt(region), _ptr(out), b, l, cv,
+                                        float(scale if scale is not None else c ** -0.5), _stream()))
+    return out
+
+
+def local_corr_softmax(f0, f1, h, w, radius):
+    _f32c(f0, f1)
+    b = f0.shape[0]
+    flow = torch.empty((b, 2, h, w), dtype=torch.float32, device=f0.device)
+    check(lib().ct_local_corr_softmax_f32(_ptr(f0), _ptr(f1), _ptr(flow), b, h, w, radius, _stream()))
+    return flow
+
+
+def local_corr_flow(f0, f1, flow, radius):
+    _f32c(f0, f1, flow)
+    b, _, h, w = flow.shape
+    corr = torch.empty((b, (2 * radius + 1) ** 2, h, w), dtype=torch.float32, device=f0.device)
+    check(lib().ct_local_corr_flow_f32(_ptr(f0), _ptr(f1), _ptr(flow), _ptr(corr), b, h, w, radius, _stream()))
+    return corr
+
+
+def local_attn_prop(q, k, flow, radius):
+    _f32c(q, k, flow)
+    b, _, h, w = flow.shape
+    out = torch.empty_like(flow)
+    check(lib().ct_local_attn_prop_f32(_ptr(q), _ptr(k), _ptr(flow), _ptr(out), b, h, w, radius, _stream()))
+    return out
+
+
+def bilinear_resize(x, size, mul0=1.0, mul1=1.0):
+    _f32c(x)
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, size[0], size[1]), dtype=torch.float32, device=x.device)
+    check(lib().ct_bilinear_resize_f32(_ptr(x), _ptr(out), n, c, h, w, size[0], size[1], float(mul0), float(mul1), _stream()))
+    return out
+
+
+def flow_warp(img, flow):
+    _f32c(img, flow)
+    n, c, h, w = img.shape
+    out = torch.empty_like(img)
+    check(lib().ct_flow_warp_f32(_ptr(img), _ptr(flow), _ptr(out), n, c, h, w, _stream()))
+    return out
+
+
+def convex_upsample(flow, mask, factor):
+    _f32c(flow, mask)
+    b, _, h, w = flow.shape
+    out = torch.empty((b, 2, h * factor, w * factor), dtype=torch.float32, device=flow.device)
+    check(lib().ct_convex_upsample_f32(_ptr(flow), _ptr(mask), _ptr(out), b, h, w, factor, _stream()))
+    return out
+
+
+def fb_check(fwd, bwd, alpha=0.01, beta=0.5):
+    """forward_backward_consistency_check (geometry.py:78-99) -> (fwd_occ, bwd_occ) [B,H,W] as 0/1 floats"""
+    _f32c(fwd, bwd)
+    b, _, h, w = fwd.shape
+    wb, wf = flow_warp(bwd, fwd), flow_warp(fwd, bwd)
+    fo = torch.empty((b, h, w), dtype=torch.float32, device=fwd.device)
+    bo = torch.empty_like(fo)
+    check(lib().ct_fb_check_f32(_ptr(fwd), _ptr(bwd), _ptr(wb), _ptr(wf), _ptr(fo), _ptr(bo), b, h, w, alpha, beta, _stream()))
+    return fo, bo

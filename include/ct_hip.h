@@ -158,6 +158,60 @@ size_t ct_pam_workspace_bytes(int n, int h, int w);
 int ct_pam_valid_f32(const float *q, const float *k, float *valid, float *colsum, float *att,
                      int n, int c, int h, int w, void *ws, size_t ws_bytes, void *stream);
 
+/* ---- a10-a16: GMFlow / UniMatch matcher building blocks (unimatch/ *.py, as called by methods/dmsct.py:85-94) ----
+ * float32, exact-f32 MFMA for the contractions.  "tokens" = channels-last [batch][H*W][C] (the layout the
+ * reference's transformer uses, transformer.py:238-239); everything else NCHW.
+ *
+ * ct_gconv2d_f32: Conv2d with any kernel / stride / padding / channel count (backbone.py:14-17,53,67;
+ *   trident_conv.py:64-72; reg_refine.py:16-17,33-39,65-69,104-107; unimatch.py:59). act: 0 none, 1 LeakyReLU(0.01),
+ *   2 ReLU, 3 sigmoid, 4 tanh.  wp: [kh*kw][ceil(cin/2)][2][64*ceil(cout/64)] (zero padded), bias padded likewise or NULL. */
+int ct_gconv2d_f32(const float *in, const float *wp, const float *bias, float *out, int n, int cin,
+                   int cout, int h, int w, int kh, int kw, int stride, int pad_h, int pad_w,
+                   long long in_bstride, long long out_bstride, int act, void *stream);
+/* InstanceNorm2d(affine=False) over `planes` planes of `plane` elements (backbone.py:10,34-39):
+ *   mode 0: IN(x)   1: relu(IN(x))   2: relu(skip + relu(IN(x)))                                                */
+int ct_instance_norm_f32(const float *x, const float *skip, float *y, int planes, int plane, float eps,
+                         int mode, void *stream);
+/* elementwise: op 0 a+b, 1 a*b, 2 (1-a)*b + a*c (GRU update, reg_refine.py:47,55), 3 normalize_img (utils.py:26-34),
+ *   4 a*s0, 5 tanh on channels < split / relu on the rest (unimatch.py:320-323)                                   */
+int ct_eltwise_f32(const float *a, const float *b, const float *c, float *y, long long n, int op,
+                   int plane, int chans, int split, float s0, void *stream);
+/* nn.Linear on tokens: out[t][n] = act(x[t][:] . w[n][:] + bias[n]); w in PyTorch layout [n][k]; k % 16 == 0;
+ *   act 0 none, 6 exact GELU (transformer.py:26-41; attention.py:181-182)                                          */
+int ct_linear_tokens_f32(const float *x, const float *w, const float *bias, float *out, long long tokens,
+                         int k, int n, int act, void *stream);
+/* LayerNorm(128, eps 1e-5, affine) on tokens, out = residual + LN(x) when residual != NULL (transformer.py:139-147) */
+int ct_layernorm128_f32(const float *x, const float *gamma, const float *beta, const float *residual,
+                        float *out, long long tokens, void *stream);
+/* single-head attention on tokens (C = 128), streaming softmax: out = softmax(q k^T * scale + mask) v.
+ *   cv = 128 (swin window attention, attention.py:48-107) or 2 (global correlation -> expected coordinate,
+ *   matching.py:10-39; flow propagation, attention.py:199-216).  region: NULL, or int32 [batch][len] ids;
+ *   pairs with different ids get the additive -100 of the shifted-window mask (utils.py:87-111).                  */
+int ct_attention_tokens_f32(const float *q, const float *k, const float *v, const int *region, float *out,
+                            int batch, int len, int cv, float scale, void *stream);
+/* matching.py:42-86: flow[b][2][h][w] from the softmax over the (2r+1)^2 integer neighbourhood; f0,f1 tokens       */
+int ct_local_corr_softmax_f32(const float *f0, const float *f1, float *flow, int batch, int h, int w,
+                              int radius, void *stream);
+/* matching.py:89-126: corr[b][(2r+1)^2][h][w] = f0 . bilinear(f1, pos + window + flow) / sqrt(128)               */
+int ct_local_corr_flow_f32(const float *f0, const float *f1, const float *flow, float *corr, int batch,
+                           int h, int w, int radius, void *stream);
+/* attention.py:220-256: (2r+1)^2 local window attention of flow; q = q_proj(f), k = k_proj(f) as tokens          */
+int ct_local_attn_prop_f32(const float *q, const float *k, const float *flow, float *out, int batch, int h,
+                           int w, int radius, void *stream);
+/* F.interpolate(bilinear, align_corners=True) to (ho, wo); channel 0 scaled by mul0, the others by mul1           */
+int ct_bilinear_resize_f32(const float *in, float *out, int n, int c, int h, int w, int ho, int wo,
+                           float mul0, float mul1, void *stream);
+/* geometry.py:68-75 flow_warp: bilinear sample at (x,y)+flow, zeros padding, align_corners=True                   */
+int ct_flow_warp_f32(const float *img, const float *flow, float *out, int n, int c, int h, int w,
+                     void *stream);
+/* utils.py:137-155 convex upsampling by `factor` (mask [b][9*factor^2][h][w])                                     */
+int ct_convex_upsample_f32(const float *flow, const float *mask, float *out, int b, int h, int w,
+                           int factor, void *stream);
+/* geometry.py:78-99 given flow_warp(bwd, fwd) and flow_warp(fwd, bwd): occlusion masks as 0/1 [b][h][w]          */
+int ct_fb_check_f32(const float *fwd, const float *bwd, const float *warped_bwd, const float *warped_fwd,
+                    float *fwd_occ, float *bwd_occ, int b, int h, int w, float alpha, float beta,
+                    void *stream);
+
 #ifdef __cplusplus
 }
 #endif

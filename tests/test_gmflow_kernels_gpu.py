@@ -1,0 +1,137 @@
+"""Unit parity of every GMFlow building-block kernel (csrc/gmflow.hip) against the torch op(s) of the reference it
+replaces, computed on the CPU in float64 where that is meaningful.  Tolerances are float32 rounding level."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+import torch.nn.functional as F   # noqa: E402
+
+from oracle import gmflow as og   # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import ct_hip
+    ct_hip.lib()
+    return ct_hip
+
+
+def close(a, b, msg, atol=2e-5, rtol=2e-5):
+    np.testing.assert_allclose(a.detach().cpu().double().numpy(), b.detach().double().numpy(), rtol=rtol, atol=atol, err_msg=msg)
+
+
+G = torch.Generator().manual_seed(0)
+
+
+def rnd(*shape):
+    return torch.randn(*shape, generator=G)
+
+
+@pytest.mark.parametrize("cfg", [  # (n, cin, cout, h, w, kh, kw, stride, ph, pw)
+    (2, 3, 64, 37, 70, 7, 7, 2, 3, 3), (1, 64, 96, 19, 35, 3, 3, 2, 1, 1), (1, 64, 96, 19, 35, 1, 1, 2, 0, 0),
+    (1, 128, 128, 12, 33, 3, 3, 1, 1, 1), (1, 128, 128, 13, 34, 3, 3, 2, 1, 1), (2, 384, 128, 9, 40, 1, 5, 1, 0, 2),
+    (1, 384, 128, 10, 33, 5, 1, 1, 2, 0), (1, 2, 128, 11, 37, 7, 7, 1, 3, 3), (1, 81, 256, 8, 32, 1, 1, 1, 0, 0),
+    (1, 256, 126, 8, 36, 3, 3, 1, 1, 1), (1, 256, 2, 8, 36, 3, 3, 1, 1, 1), (1, 256, 144, 8, 36, 1, 1, 1, 0, 0)])
+def test_gconv(hip, cfg):
+    n, cin, cout, h, w, kh, kw, s, ph, pw = cfg
+    x, wt, b = rnd(n, cin, h, w), rnd(cout, cin, kh, kw) / (cin * kh * kw) ** 0.5, rnd(cout)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), stride=s, padding=(ph, pw))
+    wp, bp = hip.pack_gconv_weight(wt.cuda(), b.cuda())
+    for act, fn in ((0, lambda t: t), (2, torch.relu), (3, torch.sigmoid), (4, torch.tanh)):
+        out = hip.gconv2d(x.cuda(), wp, bp, cout, (kh, kw), s, (ph, pw), act=act)
+        close(out, fn(ref), "gconv %s act %d" % (cfg, act))
+    wp, _ = hip.pack_gconv_weight(wt.cuda(), None)
+    close(hip.gconv2d(x.cuda(), wp, None, cout, (kh, kw), s, (ph, pw)), ref - b.double().view(1, -1, 1, 1), "no bias")
+
+
+def test_instance_norm(hip):
+    x, skip = rnd(2, 5, 17, 23) * 3 + 1, rnd(2, 5, 17, 23)
+    ref = F.instance_norm(x.double(), eps=1e-5)
+    close(hip.instance_norm(x.cuda(), 0), ref, "IN")
+    close(hip.instance_norm(x.cuda(), 1), torch.relu(ref), "IN+relu")
+    close(hip.instance_norm(x.cuda(), 2, skip.cuda()), torch.relu(skip.double() + torch.relu(ref)), "IN+relu+skip+relu")
+
+
+def test_eltwise(hip):
+    a, b, c = rnd(2, 6, 5, 7), rnd(2, 6, 5, 7), rnd(2, 6, 5, 7)
+    close(hip.eltwise(0, a.cuda(), b.cuda()), a + b, "add")
+    close(hip.eltwise(1, a.cuda(), b.cuda()), a * b, "mul")
+    z = torch.sigmoid(a)
+    close(hip.eltwise(2, z.cuda(), b.cuda(), c.cuda()), (1 - z) * b + z * c, "gru")
+    img = torch.rand(2, 3, 5, 7, generator=G) * 255
+    mean, std = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1), torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    close(hip.eltwise(3, img.cuda(), plane=35), (img / 255.0 - mean) / std, "normalize_img", atol=1e-5)
+    close(hip.eltwise(4, a.cuda(), s0=2.5), a * 2.5, "scale")
+    close(hip.eltwise(5, a.cuda(), plane=35, chans=6, split=3), torch.cat([torch.tanh(a[:, :3]), torch.relu(a[:, 3:])], 1), "tanh|relu")
+
+
+@pytest.mark.parametrize("t,k,n,act", [(200, 128, 128, 0), (1000, 256, 1024, 6), (77, 1024, 128, 0), (33, 128, 128, 0)])
+def test_linear_tokens(hip, t, k, n, act):
+    x, w, b = rnd(t, k), rnd(n, k) / k ** 0.5, rnd(n)
+    ref = F.linear(x.double(), w.double(), b.double())
+    if act == 6:
+        ref = F.gelu(ref)
+    close(hip.linear_tokens(x.cuda(), w.cuda(), b.cuda(), act=act), ref, "linear")
+    close(hip.linear_tokens(x.cuda(), w.cuda(), None, act=0), F.linear(x.double(), w.double()), "linear nobias")
+
+
+def test_layernorm(hip):
+    x, g, b, r = rnd(3, 50, 128) * 2 + 0.5, rnd(128), rnd(128), rnd(3, 50, 128)
+    ref = F.layer_norm(x.double(), (128,), g.double(), b.double())
+    close(hip.layernorm128(x.cuda(), g.cuda(), b.cuda()), ref, "LN")
+    close(hip.layernorm128(x.cuda(), g.cuda(), b.cuda(), r.cuda()), r.double() + ref, "res+LN")
+
+
+@pytest.mark.parametrize("b,l,cv,masked", [(2, 160, 128, False), (3, 448, 128, True), (1, 1792, 128, True), (2, 700, 2, False)])
+def test_attention_tokens(hip, b, l, cv, masked):
+    q, k, v = rnd(b, l, 128), rnd(b, l, 128), rnd(b, l, cv)
+    scores = torch.matmul(q.double(), k.double().transpose(1, 2)) / 128 ** 0.5
+    region = None
+    if masked:
+        region = torch.randint(0, 4, (b, l), generator=G, dtype=torch.int32)
+        scores = scores + torch.where(region[:, :, None] != region[:, None, :], -100.0, 0.0)
+    ref = torch.matmul(torch.softmax(scores, dim=-1), v.double())
+    out = hip.attention_tokens(q.cuda(), k.cuda(), v.cuda(), region.cuda() if masked else None)
+    close(out, ref, "attention", atol=5e-5, rtol=1e-4)
+
+
+def test_local_corr_kernels(hip):
+    b, h, w = 2, 13, 21
+    f0, f1 = rnd(b, 128, h, w), rnd(b, 128, h, w)
+    t0, t1 = f0.flatten(2).transpose(1, 2).contiguous(), f1.flatten(2).transpose(1, 2).contiguous()
+    close(hip.local_corr_softmax(t0.cuda(), t1.cuda(), h, w, 4), og.local_correlation_softmax(f0.double(), f1.double(), 4),
+          "local_correlation_softmax", atol=2e-4, rtol=1e-4)
+    flow = rnd(b, 2, h, w) * 3
+    close(hip.local_corr_flow(t0.cuda(), t1.cuda(), flow.cuda(), 4), og.local_correlation_with_flow(f0.double(), f1.double(), flow.double(), 4),
+          "local_correlation_with_flow", atol=2e-4, rtol=1e-4)
+
+
+def test_local_attn_prop(hip):
+    b, h, w = 2, 9, 14
+    f, flow = rnd(b, 128, h, w), rnd(b, 2, h, w) * 4
+    sd = {"feature_flow_attn.q_proj.weight": rnd(128, 128) / 11, "feature_flow_attn.q_proj.bias": rnd(128) * 0.1,
+          "feature_flow_attn.k_proj.weight": rnd(128, 128) / 11, "feature_flow_attn.k_proj.bias": rnd(128) * 0.1}
+    ref = og.self_attn_propagation({k: v.double() for k, v in sd.items()}, f.double(), flow.double(), 1)
+    tok = f.flatten(2).transpose(1, 2).contiguous().cuda()
+    q = hip.linear_tokens(tok, sd["feature_flow_attn.q_proj.weight"].cuda(), sd["feature_flow_attn.q_proj.bias"].cuda())
+    k = hip.linear_tokens(tok, sd["feature_flow_attn.k_proj.weight"].cuda(), sd["feature_flow_attn.k_proj.bias"].cuda())
+    close(hip.local_attn_prop(q, k, flow.cuda(), 1), ref, "local window propagation", atol=1e-4, rtol=1e-4)
+
+
+def test_resampling_kernels(hip):
+    x = rnd(2, 3, 11, 17)
+    close(hip.bilinear_resize(x.cuda(), (22, 34)), F.interpolate(x.double(), scale_factor=2, mode="bilinear", align_corners=True), "x2")
+    close(hip.bilinear_resize(x.cuda(), (16, 32)), F.interpolate(x.double(), size=(16, 32), mode="bilinear", align_corners=True), "resize")
+    fl = rnd(2, 2, 11, 17)
+    want = F.interpolate(fl.double(), size=(7, 9), mode="bilinear", align_corners=True)
+    want = torch.stack([want[:, 0] * 9 / 17, want[:, 1] * 7 / 11], 1)
+    close(hip.bilinear_resize(fl.cuda(), (7, 9), 9 / 17, 7 / 11), want, "flow rescale")
+    flow = rnd(2, 2, 11, 17) * 4
+    close(hip.flow_warp(x.cuda(), flow.cuda()), og.flow_warp(x.double(), flow.double()), "flow_warp", atol=1e-4)
+    mask = rnd(2, 9 * 16, 11, 17)
+    close(hip.convex_upsample(fl.cuda(), mask.cuda(), 4), og.upsample_flow_with_mask(fl.double(), mask.double(), 4), "convex upsample")
+    a, bw = rnd(2, 2, 11, 17) * 2, rnd(2, 2, 11, 17) * 2
+    fo, bo = hip.fb_check(a.cuda(), bw.cuda())
+    rf, rb = og.forward_backward_consistency_check(a.double(), bw.double())
+    assert (fo.cpu() == rf.float()).float().mean() > 0.99 and (bo.cpu() == rb.float()).float().mean() > 0.99
