@@ -337,3 +337,21 @@ def gmflow_forward(sd, img0, img1, inference_size, num_reg_refine=6, dbg=None): 
     fwd, bwd = flow[::2], flow[1::2]
     fwd_occ, bwd_occ = forward_backward_consistency_check(fwd, bwd)
     return {"flow": fwd, "flow_bwd": bwd, "fwd_occ": fwd_occ.unsqueeze(1), "bwd_occ": bwd_occ.unsqueeze(1)}
+
+
+# ---- methods/dmsct.py:76-114: the glue around the matcher (D1).  The smp encoder / decoder / head are third-party
+# code absent offline ("parity unpinned"); this restates everything between them. -------------------
+def dmsct_pad_size(shape, encoder_depth=4):                         # dmsct.py:76-82
+    f = 2 ** encoder_depth
+    return [0, (shape[-1] % f != 0) * (f - shape[-1] % f), 0, (shape[-2] % f != 0) * (f - shape[-2] % f)]
+
+
+def dmsct_fuse_features(flow, fwd_occ, features_target, features_reference, pad_size):   # dmsct.py:99-114
+    flow = F.pad(flow, pad_size, mode="replicate")
+    occ = F.pad(fwd_occ, pad_size, mode="replicate")
+    out = []
+    for idx, (ft, fr) in enumerate(zip(features_target, features_reference)):
+        s = 2.0 ** -idx
+        fl = F.interpolate(flow, scale_factor=s, mode="bilinear", align_corners=True) * s      # unimatch.py:84-90
+        out.append(torch.cat([ft, flow_warp(fr, fl), F.interpolate(1 - occ, mode="nearest", scale_factor=s)], dim=1))
+    return out

@@ -60,3 +60,49 @@ def test_gmflow_rejects_other_configurations(golden_dir):
     x = torch.rand(1, 3, 64, 64).cuda()
     with pytest.raises(NotImplementedError):
         m(x, x)                                    # pred_bidir_flow=False is not DMSCT's call
+
+
+def test_dmsct_glue_vs_oracle(golden_dir):
+    """D1 (methods/dmsct.py:96-114): padding, per-scale flow rescale + warp + occlusion resize + concat, with a
+    synthetic feature pyramid standing in for the (unavailable) smp encoder."""
+    from methods.dmsct import DMSCT
+    from oracle import gmflow as og
+    gen = torch.Generator().manual_seed(3)
+    h, w = 70, 100                                     # not a multiple of 16 -> replicate padding to 80 x 112
+    flow = torch.randn(1, 2, h, w, generator=gen) * 4
+    occ = (torch.rand(1, 1, h, w, generator=gen) > 0.7).float()
+    chans = (3, 32, 24, 48, 120)                       # smp EfficientNet-B2 out_channels at depth 4 (SURVEY 2.2 D)
+    pad = og.dmsct_pad_size((1, 3, h, w))
+    assert pad == [0, 12, 0, 10]
+    H, W = h + pad[3], w + pad[1]
+    ft = [torch.randn(1, c, H >> i, W >> i, generator=gen) for i, c in enumerate(chans)]
+    fr = [torch.randn(1, c, H >> i, W >> i, generator=gen) for i, c in enumerate(chans)]
+    want = og.dmsct_fuse_features(flow.double(), occ.double(), [t.double() for t in ft], [t.double() for t in fr], pad)
+    got = DMSCT.fuse_features(flow.cuda(), occ.cuda(), [t.cuda() for t in ft], [t.cuda() for t in fr], pad)
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert a.shape == b.shape and a.shape[1] == 2 * chans[i] + 1
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=1e-4, atol=1e-4, err_msg="scale %d" % i)
+    assert DMSCT.derive_matcher_inference_size((1, 3, 540, 960)) == [512, 896]
+
+
+def test_dmsct_forward_with_injected_modules():
+    """End to end with stand-in encoder/decoder/head modules (smp's calling convention), and the loud failure without."""
+    from methods.dmsct import DMSCT
+
+    class Enc(torch.nn.Module):
+        def forward(self, x):
+            return [x] + [torch.nn.functional.avg_pool2d(x, 2 ** i).repeat(1, 2, 1, 1) for i in range(1, 5)]
+
+    class Dec(torch.nn.Module):
+        def forward(self, *f):
+            return f[0]
+
+    class Head(torch.nn.Module):
+        def forward(self, x):
+            return 0.1 * x[:, :3] - 0.05 * x[:, 3:6]
+
+    t, r = torch.rand(1, 3, 70, 100).cuda(), torch.rand(1, 3, 70, 100).cuda()
+    out = DMSCT(encoder=Enc(), decoder=Dec(), head=Head()).cuda()(t, r)
+    assert out.shape == t.shape and out.min() >= 0 and out.max() <= 1 and torch.isfinite(out).all()
+    with pytest.raises(NotImplementedError):
+        DMSCT().cuda()(t, r)
