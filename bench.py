@@ -145,13 +145,21 @@ def main():
         t_stats = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
         t_apply = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) * 1e-3
         kern = {
-            "moments_kernel<float,true>": {"bytes": 2 * B * PLANE_F32, "t": t_stats},
+            "moments_kernel<float,true> (+ its 5 us finishing kernel)": {"bytes": 2 * B * PLANE_F32, "t": t_stats},
             "reinhard_apply_kernel<float,false>": {"bytes": 2 * B * PLANE_F32, "t": t_apply},
         }
         dom = max(kern, key=lambda k: kern[k]["t"])
         ach = kern[dom]["bytes"] / kern[dom]["t"]
+        # HBM traffic per launch of the dominant kernel from the committed PMC profile (separate --pmc passes,
+        # FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md "HBM"), valid for the same pairs-per-step only
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("pairs_per_step") == B:
+                traffic = tj.get("moments_kernel_hbm_bytes_per_launch")
         roof = {"bound": "hbm", "kernel": dom, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": ach / HBM_PEAK, "traffic": None,
+                "frac": ach / HBM_PEAK, "traffic": traffic,
                 "algorithmic_bytes_per_launch": kern[dom]["bytes"], "avg_launch_s": kern[dom]["t"],
                 "kernels": {k: {"GB/s": v["bytes"] / v["t"] / 1e9, "avg_launch_us": v["t"] * 1e6,
                                 "algorithmic_bytes_per_launch": v["bytes"]} for k, v in kern.items()},
@@ -187,6 +195,22 @@ def main():
             extra["dcmcs3di_512_pairs_per_s_f32"] = dc
             extra["dcmcs3di_512_tflops"] = flop * dc / 1e12
             extra["dcmcs3di_512_frac_fp32_mfma_peak"] = flop * dc / 157.3e12
+            # the size BASELINE.json's metric names: 1920x1080 (H*W*(6591040 + 390*W) FLOP/pair)
+            l1080, r1080 = torch.rand(1, 3, H, W, device=device), torch.rand(1, 3, H, W, device=device)
+            dc2 = rate(lambda: net(l1080, r1080, inference=True), n=2)
+            flop2 = H * W * (6591040 + 390 * W)
+            extra["dcmcs3di_1080p_pairs_per_s_f32"] = dc2
+            extra["dcmcs3di_1080p_frac_fp32_mfma_peak"] = flop2 * dc2 / 157.3e12
+            del net, l1080, r1080
+            # configs[3]: GMFlow matcher as DMSCT calls it (bidirectional + occlusion), random init, 540x960 -> 512x896
+            from unimatch import GMFlow
+            from methods.dmsct import DMSCT
+            gm = GMFlow().to(device)
+            a960, b960 = torch.rand(1, 3, 540, 960, device=device) * 255, torch.rand(1, 3, 540, 960, device=device) * 255
+            size = DMSCT.derive_matcher_inference_size(a960.shape)
+            gr = rate(lambda: gm(a960, b960, inference_size=size, pred_bidir_flow=True, fwd_bwd_consistency_check=True), n=3)
+            extra["gmflow_960x540_pairs_per_s_f32"] = gr
+            extra["gmflow_960x540_frac_fp32_mfma_peak"] = 3.58357106688e12 * gr / 157.3e12
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
