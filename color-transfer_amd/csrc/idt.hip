@@ -22,6 +22,7 @@ namespace ct {
 
 constexpr int kIdtMaxBins = 1024;   // 3*bins*16 B of LUT in LDS (48 KiB) per workgroup
 constexpr int kIdtBlock = 256;
+constexpr int kIdtHistBlock = 1024;   // few workgroups (few contended atomic flushes) but many waves per CU
 
 // ---- order-preserving key for float64 (atomicMax on u64; zero-initialised memory = "-inf") ----
 __device__ __forceinline__ unsigned long long f64_key(double x) {
@@ -165,13 +166,13 @@ __global__ void idt_params_kernel(const unsigned long long *__restrict__ mm, dou
 // A7: histograms of both images on the three rotated axes. grid = (G, batch), dynamic LDS = 6*bins*4 B
 // -------------------------------------------------------------------------------------------
 template <typename TT, typename TR>
-__global__ __launch_bounds__(kIdtBlock) void idt_hist_kernel(const TT *__restrict__ tgt, int64_t n_t, const TR *__restrict__ ref,
+__global__ __launch_bounds__(kIdtHistBlock) void idt_hist_kernel(const TT *__restrict__ tgt, int64_t n_t, const TR *__restrict__ ref,
                                                              int64_t n_r, const double *__restrict__ rot,
                                                              const double *__restrict__ par, int n_iter, int it, int bins,
                                                              unsigned int *__restrict__ hist, unsigned short *__restrict__ binidx) {
     extern __shared__ unsigned int lh[];  // [2][3][bins]
     const int b = blockIdx.y;
-    for (int i = threadIdx.x; i < 6 * bins; i += kIdtBlock) lh[i] = 0;
+    for (int i = threadIdx.x; i < 6 * bins; i += kIdtHistBlock) lh[i] = 0;
     double r[9], lo[3], hi[3], step[3], scale[3];
 #pragma unroll
     for (int i = 0; i < 9; ++i) r[i] = rot[((size_t)b * n_iter + it) * 9 + i];
@@ -181,9 +182,9 @@ __global__ __launch_bounds__(kIdtBlock) void idt_hist_kernel(const TT *__restric
         lo[j] = q[0]; hi[j] = q[1]; step[j] = q[2]; scale[j] = q[3];
     }
     __syncthreads();
-    const int64_t stride = (int64_t)gridDim.x * kIdtBlock;
+    const int64_t stride = (int64_t)gridDim.x * kIdtHistBlock;
     const TT *pt = tgt + (size_t)b * n_t * 3;
-    for (int64_t i = (int64_t)blockIdx.x * kIdtBlock + threadIdx.x; i < n_t; i += stride) {
+    for (int64_t i = (int64_t)blockIdx.x * kIdtHistBlock + threadIdx.x; i < n_t; i += stride) {
         const double x0 = (double)pt[3 * i], x1 = (double)pt[3 * i + 1], x2 = (double)pt[3 * i + 2];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(kIdtBlock) void idt_hist_kernel(const TT *__restric
         }
     }
     const TR *pr = ref + (size_t)b * n_r * 3;
-    for (int64_t i = (int64_t)blockIdx.x * kIdtBlock + threadIdx.x; i < n_r; i += stride) {
+    for (int64_t i = (int64_t)blockIdx.x * kIdtHistBlock + threadIdx.x; i < n_r; i += stride) {
         const double x0 = (double)pr[3 * i], x1 = (double)pr[3 * i + 1], x2 = (double)pr[3 * i + 2];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(kIdtBlock) void idt_hist_kernel(const TT *__restric
     }
     __syncthreads();
     unsigned int *gh = hist + ((size_t)b * n_iter + it) * 6 * bins;
-    for (int i = threadIdx.x; i < 6 * bins; i += kIdtBlock) {
+    for (int i = threadIdx.x; i < 6 * bins; i += kIdtHistBlock) {
         const unsigned int c = lh[i];
         if (c) atomicAdd(gh + i, c);
     }
@@ -221,12 +222,28 @@ __global__ __launch_bounds__(kIdtBlock) void idt_lut_kernel(const unsigned int *
     const unsigned int *h1 = hist + (((size_t)b * n_iter + it) * 6 + 3 + j) * bins;
     const double *q = par + (((size_t)b * n_iter + it) * 3 + j) * 4;
     const double lo = q[0], hi = q[1], step = q[2];
-    // exact integer prefix sums; two lanes walk the two histograms (<= 2048 bins: a few microseconds)
-    if (threadIdx.x < 2) {
-        const unsigned int *h = threadIdx.x ? h1 : h0;
-        double *cp = threadIdx.x ? cp1 : cp0;
-        unsigned long long c = 0;
-        for (int i = 0; i < bins; ++i) { c += h[i]; cp[i] = (double)c; }
+    // exact integer prefix sums of both histograms: each thread owns a contiguous segment (<= 4 bins for
+    // bins <= 1024), a Hillis-Steele scan over the 256 segment totals in LDS, then the segment is re-walked
+    __shared__ unsigned long long seg[2][kIdtBlock];
+    const int per = (bins + kIdtBlock - 1) / kIdtBlock;
+    const int b0 = threadIdx.x * per;
+    unsigned long long s0 = 0, s1 = 0;
+    for (int i = b0; i < b0 + per && i < bins; ++i) { s0 += h0[i]; s1 += h1[i]; }
+    seg[0][threadIdx.x] = s0; seg[1][threadIdx.x] = s1;
+    __syncthreads();
+    for (int off = 1; off < kIdtBlock; off <<= 1) {
+        unsigned long long a0 = 0, a1 = 0;
+        if ((int)threadIdx.x >= off) { a0 = seg[0][threadIdx.x - off]; a1 = seg[1][threadIdx.x - off]; }
+        __syncthreads();
+        seg[0][threadIdx.x] += a0; seg[1][threadIdx.x] += a1;
+        __syncthreads();
+    }
+    {
+        unsigned long long c0 = seg[0][threadIdx.x] - s0, c1 = seg[1][threadIdx.x] - s1;   // exclusive prefix of this segment
+        for (int i = b0; i < b0 + per && i < bins; ++i) {
+            c0 += h0[i]; cp0[i] = (double)c0;
+            c1 += h1[i]; cp1[i] = (double)c1;
+        }
     }
     __syncthreads();
     const double t0 = cp0[bins - 1], t1 = cp1[bins - 1];
@@ -404,16 +421,19 @@ static int idt_impl(const T *target, int64_t n_t, const T *reference, int64_t n_
     hipLaunchKernelGGL((idt_minmax_kernel<T, 8>), dim3(gt, batch), dim3(kIdtBlock), 0, s, target, n_t, rot, n_iter, 0, 1, 0,
                        l.mm);
     CT_CHECK_LAUNCH();
-    const int gh = idt_grid(n_t > n_r ? n_t : n_r, batch);
+    // the histogram flush is 6*bins global integer atomics per workgroup onto the SAME addresses: keep the grid at
+    // ~2 workgroups per CU (contended same-address atomics are an order of magnitude slower, MI355X_MICROARCH.md)
+    int gh = idt_grid((n_t > n_r ? n_t : n_r) / 4 + 1, batch);
+    { int cap = 1024 / batch; cap = cap > 512 ? 512 : (cap < 64 ? 64 : cap); if (gh > cap) gh = cap; }   // per pair
     for (int it = 0; it < n_iter; ++it) {
         hipLaunchKernelGGL(idt_params_kernel, dim3(batch), dim3(64), 0, s, l.mm, l.par, n_iter, it, bins);
         CT_CHECK_LAUNCH();
         unsigned short *bi = (dbg && dbg->binidx) ? dbg->binidx : nullptr;
         if (it == 0) {
-            hipLaunchKernelGGL((idt_hist_kernel<T, T>), dim3(gh, batch), dim3(kIdtBlock), 6 * bins * sizeof(unsigned int), s,
+            hipLaunchKernelGGL((idt_hist_kernel<T, T>), dim3(gh, batch), dim3(kIdtHistBlock), 6 * bins * sizeof(unsigned int), s,
                                target, n_t, reference, n_r, rot, l.par, n_iter, it, bins, l.hist, bi);
         } else {
-            hipLaunchKernelGGL((idt_hist_kernel<double, T>), dim3(gh, batch), dim3(kIdtBlock),
+            hipLaunchKernelGGL((idt_hist_kernel<double, T>), dim3(gh, batch), dim3(kIdtHistBlock),
                                6 * bins * sizeof(unsigned int), s, (const double *)out, n_t, reference, n_r, rot, l.par,
                                n_iter, it, bins, l.hist, bi);
         }
