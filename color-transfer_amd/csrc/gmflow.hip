@@ -257,11 +257,13 @@ __global__ __launch_bounds__(256) void layernorm_tokens_kernel(const float *__re
 // q/k/v rows are fetched with 16-byte loads (a lane needs C/2 consecutive channels of one token row).
 // grid = (ceil(L/128), B); block = 4 waves.
 // =================================================================================================
-template <int CV>
+template <int C, int CV>
 __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                                const float *__restrict__ v, const int *__restrict__ region,
-                                                               float *__restrict__ out, int L, float scale) {
-    constexpr int C = 128;
+                                                               float *__restrict__ out, float *__restrict__ stats, int L,
+                                                               float scale) {
+    constexpr int CH = C / 2;            // channels per lane half
+    constexpr int NVT = CV >= 32 ? CV / 32 : 1;   // 32-channel value tiles on the MFMA path
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nl = lane & 31, hl = lane >> 5;
     const int b = blockIdx.y;
     const int q0 = (blockIdx.x * 4 + wave) * 32;
@@ -269,35 +271,35 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
     const size_t tb = (size_t)b * L;
     const int qi = q0 + nl;
     const bool qlive = qi < L;
-    // B operand of S^T = K Q^T : lane (query nl, half hl) holds q[query][hl*64 + p], p < 64
-    float qb[64];
+    // B operand of S^T = K Q^T : lane (query nl, half hl) holds q[query][hl*C/2 + p], p < C/2
+    float qb[CH];
     {
-        const float *qp = q + (tb + (qlive ? qi : L - 1)) * C + hl * 64;
+        const float *qp = q + (tb + (qlive ? qi : L - 1)) * C + hl * CH;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < CH / 4; ++i) {
             const float4 t = *reinterpret_cast<const float4 *>(qp + 4 * i);
             qb[4 * i] = t.x * scale; qb[4 * i + 1] = t.y * scale; qb[4 * i + 2] = t.z * scale; qb[4 * i + 3] = t.w * scale;
         }
     }
     const int qreg = region ? region[tb + (qlive ? qi : L - 1)] : 0;
     float m_run = -INFINITY, l_run = 0.f;
-    f32x16g o[CV == 128 ? 4 : 1];
+    f32x16g o[NVT];
     float o2x = 0.f, o2y = 0.f;
-    if (CV == 128) {
+    if (CV >= 32) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NVT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
     }
     for (int j0 = 0; j0 < L; j0 += 32) {
         // ---- S^T tile: A = K rows (key nl), B = Q ----
         const int kj = j0 + nl;
-        const float *kp = k + (tb + (kj < L ? kj : L - 1)) * C + hl * 64;
+        const float *kp = k + (tb + (kj < L ? kj : L - 1)) * C + hl * CH;
         f32x16g s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < CH / 4; ++i) {
             const float4 t = *reinterpret_cast<const float4 *>(kp + 4 * i);
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(t.x, qb[4 * i], s, 0, 0, 0);
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(t.y, qb[4 * i + 1], s, 0, 0, 0);
@@ -328,9 +330,9 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
         psum += __shfl_xor(psum, 32, 64);
         l_run = l_run * corr + psum;
         m_run = m_new;
-        if (CV == 128) {
+        if (CV >= 32) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NVT; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[j][r] *= corr;
             // O^T[c][query] += sum_key V[key][c] P[key][query]: k-step r pairs the keys held by the two lane halves
@@ -338,11 +340,11 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-                const float *vp = v + (tb + (key < L ? key : L - 1)) * C + nl;
+                const float *vp = v + (tb + (key < L ? key : L - 1)) * CV + nl;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * j], s[r], o[j], 0, 0, 0);
+                for (int j = 0; j < NVT; ++j) o[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * j], s[r], o[j], 0, 0, 0);
             }
-        } else {
+        } else if (CV == 2) {
             float ax = 0.f, ay = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -358,17 +360,74 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
         }
     }
     const float inv = 1.0f / l_run;
-    if (CV == 128) {
+    if (stats && qlive && hl == 0) {     // row statistics of the softmax (max, sum): used by the column-sum pass
+        stats[(tb + qi) * 2] = m_run;
+        stats[(tb + qi) * 2 + 1] = l_run;
+    }
+    if (CV >= 32) {
         // O^T[c][query]: lane = query nl, registers = channels (r&3)+8(r>>2)+4hl of tile j
         if (qlive) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NVT; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) out[(tb + qi) * C + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl] = o[j][r] * inv;
+                for (int r = 0; r < 16; ++r) out[(tb + qi) * CV + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl] = o[j][r] * inv;
         }
-    } else {
+    } else if (CV == 2) {
         if (qlive && hl == 0) *reinterpret_cast<float2 *>(out + (tb + qi) * 2) = make_float2(o2x * inv, o2y * inv);
     }
+}
+
+// Column sums of a row-softmax, given its row statistics: colsum[b][j] = sum_i exp(scale q_i.k_j - m_i) / l_i
+// (pasmnet/utils.py:31,34: att_left2right.sum(dim=-2)).  One wave per 32 keys; the score tile is computed in the
+// natural orientation (queries on the MFMA rows = registers, the key on the lane), so the sum over queries is a
+// sum over registers plus one cross-half shuffle, in a fixed order (deterministic).
+template <int C>
+__global__ __launch_bounds__(256) void attention_colsum_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                               const float *__restrict__ stats, float *__restrict__ colsum, int L,
+                                                               float scale) {
+    constexpr int CH = C / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nl = lane & 31, hl = lane >> 5;
+    const int b = blockIdx.y;
+    const int j0 = (blockIdx.x * 4 + wave) * 32;
+    if (j0 >= L) return;
+    const size_t tb = (size_t)b * L;
+    const int kj = j0 + nl;
+    float kb[CH];                                   // B operand: this lane's key row
+    {
+        const float *kp = k + (tb + (kj < L ? kj : L - 1)) * C + hl * CH;
+#pragma unroll
+        for (int i = 0; i < CH / 4; ++i) {
+            const float4 t = *reinterpret_cast<const float4 *>(kp + 4 * i);
+            kb[4 * i] = t.x * scale; kb[4 * i + 1] = t.y * scale; kb[4 * i + 2] = t.z * scale; kb[4 * i + 3] = t.w * scale;
+        }
+    }
+    float acc = 0.f;
+    for (int i0 = 0; i0 < L; i0 += 32) {
+        const int qi = i0 + nl;
+        const float *qp = q + (tb + (qi < L ? qi : L - 1)) * C + hl * CH;
+        f32x16g s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH / 4; ++i) {
+            const float4 t = *reinterpret_cast<const float4 *>(qp + 4 * i);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(t.x, kb[4 * i], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(t.y, kb[4 * i + 1], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(t.z, kb[4 * i + 2], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(t.w, kb[4 * i + 3], s, 0, 0, 0);
+        }
+        // lane: key nl; s[r] = score of query i0 + (r&3)+8(r>>2)+4hl
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qq = i0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+            if (qq < L) {
+                const float2 ml = *reinterpret_cast<const float2 *>(stats + (tb + qq) * 2);
+                acc += expf(s[r] - ml.x) / ml.y;
+            }
+        }
+    }
+    acc += __shfl_xor(acc, 32, 64);
+    if (hl == 0 && kj < L) colsum[tb + kj] = acc;
 }
 
 // =================================================================================================
@@ -701,8 +760,33 @@ int ct_attention_tokens_f32(const float *q, const float *k, const float *v, cons
     if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k)) & 15) return CT_E_ALIGN;
     if (batch == 0) return CT_OK;
     dim3 grid((len + 127) / 128, batch);
-    if (cv == 128) hipLaunchKernelGGL((ct::attention_tokens_kernel<128>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, region, out, len, scale);
-    else hipLaunchKernelGGL((ct::attention_tokens_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, region, out, len, scale);
+    float *nostats = nullptr;
+    if (cv == 128) hipLaunchKernelGGL((ct::attention_tokens_kernel<128, 128>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, region, out, nostats, len, scale);
+    else hipLaunchKernelGGL((ct::attention_tokens_kernel<128, 2>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, region, out, nostats, len, scale);
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+}
+
+int ct_attention_rows64_f32(const float *q, const float *k, const float *v, float *out, float *stats, int batch, int len, float scale,
+                            void *stream) {
+    if (!q || !k || batch < 0 || len < 1 || (v && !out) || (!v && !stats)) return CT_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k)) & 15) return CT_E_ALIGN;
+    if (batch == 0) return CT_OK;
+    dim3 grid((len + 127) / 128, batch);
+    const int *noreg = nullptr;
+    if (v) hipLaunchKernelGGL((ct::attention_tokens_kernel<64, 96>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, noreg, out, stats, len, scale);
+    else hipLaunchKernelGGL((ct::attention_tokens_kernel<64, 0>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, noreg, out, stats, len, scale);
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+}
+
+int ct_attention_colsum64_f32(const float *q, const float *k, const float *stats, float *colsum, int batch, int len, float scale,
+                              void *stream) {
+    if (!q || !k || !stats || !colsum || batch < 0 || len < 1) return CT_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k)) & 15) return CT_E_ALIGN;
+    if (batch == 0) return CT_OK;
+    dim3 grid((len + 127) / 128, batch);
+    hipLaunchKernelGGL((ct::attention_colsum_kernel<64>), grid, dim3(256), 0, (hipStream_t)stream, q, k, stats, colsum, len, scale);
     CT_CHECK_LAUNCH();
     return CT_OK;
 }

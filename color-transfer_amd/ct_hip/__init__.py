@@ -351,6 +351,8 @@ SIGNATURES.update({
     "ct_linear_tokens_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p]),
     "ct_layernorm128_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_p]),
     "ct_attention_tokens_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_p]),
+    "ct_attention_rows64_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_f, _c_p]),
+    "ct_attention_colsum64_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_f, _c_p]),
     "ct_local_corr_softmax_f32": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "ct_local_corr_flow_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "ct_local_attn_prop_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
@@ -505,3 +507,34 @@ def fb_check(fwd, bwd, alpha=0.01, beta=0.5):
     bo = torch.empty_like(fo)
     check(lib().ct_fb_check_f32(_ptr(fwd), _ptr(bwd), _ptr(wb), _ptr(wf), _ptr(fo), _ptr(bo), b, h, w, alpha, beta, _stream()))
     return fo, bo
+
+
+def pam_streaming(q, k, v, rgb, q_other, k_other):
+    """DCMCS3DI's parallax attention through the streaming kernels (any width):
+    q,k [B,64,H,W] = Q(left), K(right); v [B,64,H,W], rgb [B,3,H,W]; q_other,k_other = Q(right), K(left).
+    Returns (fea_warped [B,64,H,W], warped_rgb [B,3,H,W], valid [B,1,H,W] 0/1, colsum [B,1,H,W])."""
+    _f32c(q, k, v, rgb, q_other, k_other)
+    b, c, h, w = q.shape
+    if c != 64 or v.shape[1] != 64:
+        raise CtHipError("pam_streaming is built for 64 channels")
+    scale = 1.0 / c                                   # the reference scales by 1/c, not 1/sqrt(c) (attention.py:41)
+
+    def rows(t):                                      # [B,C,H,W] -> [B*H, W, C] tokens (data movement only)
+        return t.permute(0, 2, 3, 1).reshape(b * h, w, t.shape[1]).contiguous()
+    qt, kt = rows(q), rows(k)
+    vt = torch.zeros((b * h, w, 96), dtype=torch.float32, device=q.device)
+    vt[:, :, :64] = rows(v)
+    vt[:, :, 64:67] = rows(rgb)
+    out = torch.empty((b * h, w, 96), dtype=torch.float32, device=q.device)
+    check(lib().ct_attention_rows64_f32(_ptr(qt), _ptr(kt), _ptr(vt), _ptr(out), _c_p(0), b * h, w, scale, _stream()))
+    out = out.view(b, h, w, 96)
+    fea = out[..., :64].permute(0, 3, 1, 2).contiguous()
+    wrgb = out[..., 64:67].permute(0, 3, 1, 2).contiguous()
+    qo, ko = rows(q_other), rows(k_other)
+    stats = torch.empty((b * h, w, 2), dtype=torch.float32, device=q.device)
+    check(lib().ct_attention_rows64_f32(_ptr(qo), _ptr(ko), _c_p(0), _c_p(0), _ptr(stats), b * h, w, scale, _stream()))
+    colsum = torch.empty((b * h, w), dtype=torch.float32, device=q.device)
+    check(lib().ct_attention_colsum64_f32(_ptr(qo), _ptr(ko), _ptr(stats), _ptr(colsum), b * h, w, scale, _stream()))
+    colsum = colsum.view(b, 1, h, w)
+    valid = (colsum > 0.1).float()                    # threshold only (utils.py:34); the sums come from the kernel
+    return fea, wrgb, valid, colsum

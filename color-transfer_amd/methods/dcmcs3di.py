@@ -14,28 +14,21 @@ from pasmnet.attention import PAB
 from pasmnet.backbone import ResB
 
 
-class _Packed:
-    """Packed (MFMA operand layout) copies of a module's conv weights, rebuilt when parameters change."""
-
-    def __init__(self):
-        self.cache = {}
-
-    def get(self, conv):
-        key = id(conv)
-        ver = (conv.weight._version, conv.weight.data_ptr(), conv.bias._version if conv.bias is not None else -1,
-               str(conv.weight.device))
-        hit = self.cache.get(key)
-        if hit is None or hit[0] != ver:
-            hit = (ver, ct_hip.pack_conv_weight(conv.weight, conv.bias))
-            self.cache[key] = hit
-        return hit[1]
-
-
-_packed = _Packed()
+def _packed_conv(conv):
+    """Packed (MFMA operand layout) copy of a conv's weights, cached ON the module and rebuilt when its parameters
+    change (in-place update -> _version, load_state_dict / .to() -> data_ptr).  A global cache keyed by id() would
+    hand a new module the packed weights of a dead one whose id and storage were recycled."""
+    ver = (conv.weight._version, conv.weight.data_ptr(), -1 if conv.bias is None else conv.bias._version,
+           -1 if conv.bias is None else conv.bias.data_ptr(), str(conv.weight.device))
+    hit = getattr(conv, "_ct_packed", None)
+    if hit is None or hit[0] != ver:
+        hit = (ver, ct_hip.pack_conv_weight(conv.weight, conv.bias))
+        conv._ct_packed = hit
+    return hit[1]
 
 
 def conv_forward(conv, x, act=0, residual=None, clamp=False, out=None):
-    wp, b = _packed.get(conv)
+    wp, b = _packed_conv(conv)
     return ct_hip.conv2d(x, wp, b, conv.out_channels, conv.kernel_size[0], act=act, residual=residual, clamp=clamp,
                          out=out)
 
@@ -90,10 +83,17 @@ class DCMCS3DI(torch.nn.Module):
         k = conv_forward(self.matcher.key, head)                           # attention.py:40,45
         fea_left, fea_right = fea[:B], fea[B:]
         v = conv_forward(self.matcher.value, fea_right)                    # dcmcs3di.py:58
-        # right-to-left: Q(left) . K(right)
-        fea_warped, warped_rgb, att_r2l = ct_hip.pam_attend(q[:B], k[B:], v, right, want_att=want_att)
-        # left-to-right softmax, column sums -> valid mask of the LEFT view (utils.py:31,34-35)
-        valid_left, colsum_left, att_l2r = ct_hip.pam_valid(q[B:], k[:B], want_att=want_att)
+        if want_att:
+            # the [B,H,W,W] maps are wanted: LDS-tile kernels that can write them out
+            # right-to-left: Q(left) . K(right)
+            fea_warped, warped_rgb, att_r2l = ct_hip.pam_attend(q[:B], k[B:], v, right, want_att=True)
+            # left-to-right softmax, column sums -> valid mask of the LEFT view (utils.py:31,34-35)
+            valid_left, colsum_left, att_l2r = ct_hip.pam_valid(q[B:], k[:B], want_att=True)
+        else:
+            # streaming (online-softmax) kernels: no score tile in LDS, any width, K/V rows fetched with 16-byte loads
+            att_r2l = att_l2r = None
+            fea_warped, warped_rgb, valid_left, colsum_left = ct_hip.pam_streaming(
+                q[:B].contiguous(), k[B:].contiguous(), v, right, q[B:].contiguous(), k[:B].contiguous())
         x = torch.cat([fea_left, fea_warped, valid_left], dim=1)           # dcmcs3di.py:59 (bool -> float)
         n_t = len(self.transfer)
         for i in range(n_t - 1):

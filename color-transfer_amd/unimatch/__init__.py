@@ -124,28 +124,23 @@ class BasicUpdateBlock(nn.Module):                    # unimatch/reg_refine.py:8
 
 
 # ---- packed weights ----------------------------------------------------------------------------------------------
-class _Packed:
-    def __init__(self):
-        self.cache = {}
-
-    def conv(self, weight, bias):
-        key = id(weight)
-        ver = (weight._version, weight.data_ptr(), None if bias is None else bias._version, str(weight.device))
-        hit = self.cache.get(key)
-        if hit is None or hit[0] != ver:
-            hit = (ver, ct_hip.pack_gconv_weight(weight, bias))
-            self.cache[key] = hit
-        return hit[1]
-
-
-_packed = _Packed()
+def _packed_conv(weight, bias):
+    """ct_gconv2d_f32 operand layout of a conv's parameters, cached ON the weight Parameter and rebuilt when the
+    parameters change (a global cache keyed by id() would serve recycled ids stale weights)."""
+    ver = (weight._version, weight.data_ptr(), -1 if bias is None else bias._version,
+           -1 if bias is None else bias.data_ptr(), str(weight.device))
+    hit = getattr(weight, "_ct_packed", None)
+    if hit is None or hit[0] != ver:
+        hit = (ver, ct_hip.pack_gconv_weight(weight, bias))
+        weight._ct_packed = hit
+    return hit[1]
 
 
 def _conv(m, x, act=ACT_NONE, stride=None, padding=None, weight=None):
     """Conv2d module (or a bare weight) -> ct_gconv2d_f32"""
     w = m.weight if weight is None else weight
     b = getattr(m, "bias", None) if weight is None else None
-    wp, bp = _packed.conv(w, b)
+    wp, bp = _packed_conv(w, b)
     st = (m.stride[0] if weight is None else 1) if stride is None else stride
     pd = (tuple(m.padding) if weight is None else 1) if padding is None else padding
     return ct_hip.gconv2d(x, wp, bp, w.shape[0], (w.shape[2], w.shape[3]), st, pd, act=act)

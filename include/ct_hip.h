@@ -189,6 +189,16 @@ int ct_layernorm128_f32(const float *x, const float *gamma, const float *beta, c
  *   pairs with different ids get the additive -100 of the shifted-window mask (utils.py:87-111).                  */
 int ct_attention_tokens_f32(const float *q, const float *k, const float *v, const int *region, float *out,
                             int batch, int len, int cv, float scale, void *stream);
+/* Streaming parallax attention on 64-channel row tokens (pasmnet/attention.py:39-46, utils.py:30-35,123-125), for
+ * image widths whose score tile does not fit LDS (ct_pam_* need w <= 1982) and as the faster path in general:
+ *   ct_attention_rows64_f32 : out[b][i][0:96] = softmax_j(q_i.k_j*scale) v[b][j][0:96]   (v != NULL), and/or the row
+ *                             statistics stats[b][i] = (max, sum) of that softmax (v == NULL: statistics only)
+ *   ct_attention_colsum64_f32: colsum[b][j] = sum_i exp(q_i.k_j*scale - max_i) / sum_i  (the valid-mask numerator),
+ *                             fixed summation order.  batch = N*H rows, len = W, tokens channels-last.                */
+int ct_attention_rows64_f32(const float *q, const float *k, const float *v, float *out, float *stats,
+                            int batch, int len, float scale, void *stream);
+int ct_attention_colsum64_f32(const float *q, const float *k, const float *stats, float *colsum,
+                              int batch, int len, float scale, void *stream);
 /* matching.py:42-86: flow[b][2][h][w] from the softmax over the (2r+1)^2 integer neighbourhood; f0,f1 tokens       */
 int ct_local_corr_softmax_f32(const float *f0, const float *f1, float *flow, int batch, int h, int w,
                               int radius, void *stream);

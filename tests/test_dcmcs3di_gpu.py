@@ -69,7 +69,9 @@ def test_forward_vs_reference_small(golden_dir, name):
     corrected, (att, att_cycle, valid, warped) = m(left, right, inference=True)
     assert att == (None, None) and att_cycle == (None, None) and valid[1] is None
     assert valid[0].dtype == torch.bool and valid[0].shape == (1, 1) + left.shape[2:]
-    assert torch.equal(corrected, p["corrected"]) and torch.equal(warped, p["warped_rgb"])
+    # inference=True takes the streaming attention kernels, forward_parts(want_att=True) the LDS-tile ones
+    assert torch.allclose(corrected, p["corrected"], atol=2e-5) and torch.allclose(warped, p["warped_rgb"], atol=2e-5)
+    close(corrected.cpu().numpy(), g[name + "/corrected"], "corrected (streaming attention path)")
     corrected2, (att2, cyc2, valid2, _) = m(left, right)            # training-style call: everything materialised
     assert att2[0].shape == (1, left.shape[2], left.shape[3], left.shape[3]) and cyc2[0] is not None
     assert valid2[1].dtype == torch.bool
@@ -125,5 +127,29 @@ def test_pam_kernels_vs_torch_reference(h, w):
     valid, colsum, _ = ct_hip.pam_valid(q.cuda(), k.cuda())
     want_cs = att.sum(dim=-2)
     close(colsum[:, 0].cpu().numpy(), want_cs.numpy(), "colsum", atol=2e-5)
+    safe = (want_cs - 0.1).abs() > 1e-3
+    assert ((valid[:, 0].cpu() > 0.5)[safe] == (want_cs > 0.1)[safe]).all()
+
+
+@pytest.mark.parametrize("h,w", [(3, 70), (2, 512), (1, 1030), (1, 2100)])
+def test_pam_streaming_vs_torch_reference(h, w):
+    """The streaming parallax-attention path (default at inference): warp of features and of the right image, and the
+    valid-mask column sums, for widths below and above the LDS-tile kernels' limit."""
+    import ct_hip
+    gen = torch.Generator().manual_seed(w + 1)
+    ql, kr, qr, kl = (torch.randn(1, 64, h, w, generator=gen) * 2 for _ in range(4))
+    v = torch.randn(1, 64, h, w, generator=gen)
+    rgb = torch.rand(1, 3, h, w, generator=gen)
+
+    def att(q, k):
+        return torch.softmax(torch.matmul(q.double().permute(0, 2, 3, 1), k.double().permute(0, 2, 1, 3)) / 64, dim=-1)
+    a_r2l, a_l2r = att(ql, kr), att(qr, kl)
+    want_v = torch.matmul(a_r2l, v.double().permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+    want_rgb = torch.matmul(a_r2l, rgb.double().permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+    want_cs = a_l2r.sum(dim=-2)
+    fea, wrgb, valid, colsum = ct_hip.pam_streaming(ql.cuda(), kr.cuda(), v.cuda(), rgb.cuda(), qr.cuda(), kl.cuda())
+    close(fea.cpu().numpy(), want_v.numpy(), "warp(v)", atol=2e-5)
+    close(wrgb.cpu().numpy(), want_rgb.numpy(), "warp(rgb)", atol=2e-5)
+    close(colsum[:, 0].cpu().numpy(), want_cs.numpy(), "colsum", atol=3e-5)
     safe = (want_cs - 0.1).abs() > 1e-3
     assert ((valid[:, 0].cpu() > 0.5)[safe] == (want_cs > 0.1)[safe]).all()
