@@ -177,7 +177,12 @@ def main():
                 torch.cuda.synchronize()
                 return n / (time.perf_counter() - t0)
             extra["mk_pairs_per_s_f64out_hostalgebra"] = rate(
-                lambda: lin.monge_kantorovitch_color_transfer_cuda(tgt[0], ref[0]))
+                lambda: lin.monge_kantorovitch_color_transfer_cuda(tgt[0], ref[0], host_algebra=True))
+            mk_out = torch.empty(tgt.shape, dtype=torch.float32, device=device)
+            extra["mk_pairs_per_s_f32out_device_algebra"] = B * rate(
+                lambda: lin.monge_kantorovitch_color_transfer_cuda(tgt, ref, out_dtype=torch.float32, out=mk_out), n=20)
+            extra["mk_frac_hbm_peak"] = ALGO_BYTES_PER_PAIR * extra["mk_pairs_per_s_f32out_device_algebra"] / HBM_PEAK
+            del mk_out
             extra["xiao_pairs_per_s_f64out_hostalgebra"] = rate(
                 lambda: lin.color_transfer_in_correlated_color_space_cuda(tgt[0], ref[0]))
             import methods.iterative as it

@@ -296,6 +296,126 @@ __global__ __launch_bounds__(kBlock) void affine3x3_kernel(const TI *__restrict_
 }
 
 // -------------------------------------------------------------------------------------------
+// A4 (sync-free variant): the 3x3 algebra of monge_kantorovitch_color_transfer on the device
+// (methods/linear.py:108-118).  One thread per pair, float64.  The matrix square root of a symmetric
+// positive (semi)definite 3x3 is V diag(sqrt(lambda)) V^T from a cyclic Jacobi eigen-decomposition;
+// it is unique, so no LAPACK sign convention is involved (Xiao's SVD-based T is NOT sign invariant
+// and stays on the host).  mode: 0 = "MK", 1 = "sqrt", 2 = "cholesky".
+// coef[b] = { T (row-major, out = (x - mu_t) @ T + mu_r), mu_t, mu_r, 0 }.
+// -------------------------------------------------------------------------------------------
+struct M3 { double a[3][3]; };
+
+__device__ inline M3 m3_mul(const M3 &x, const M3 &y) {
+    M3 r;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) r.a[i][j] = fma(x.a[i][2], y.a[2][j], fma(x.a[i][1], y.a[1][j], x.a[i][0] * y.a[0][j]));
+    return r;
+}
+
+__device__ inline void m3_eig_sym(M3 s, M3 &v, double (&lam)[3]) {   // s = v diag(lam) v^T, cyclic Jacobi
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) v.a[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        const double off = fabs(s.a[0][1]) + fabs(s.a[0][2]) + fabs(s.a[1][2]);
+        if (off == 0.0) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                const double apq = s.a[p][q];
+                if (apq == 0.0) continue;
+                const double theta = (s.a[q][q] - s.a[p][p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < 3; ++k) {   // columns p, q of s
+                    const double skp = s.a[k][p], skq = s.a[k][q];
+                    s.a[k][p] = c * skp - sn * skq;
+                    s.a[k][q] = sn * skp + c * skq;
+                }
+                for (int k = 0; k < 3; ++k) {   // rows p, q of s
+                    const double spk = s.a[p][k], sqk = s.a[q][k];
+                    s.a[p][k] = c * spk - sn * sqk;
+                    s.a[q][k] = sn * spk + c * sqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double vkp = v.a[k][p], vkq = v.a[k][q];
+                    v.a[k][p] = c * vkp - sn * vkq;
+                    v.a[k][q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < 3; ++i) lam[i] = s.a[i][i];
+}
+
+__device__ inline M3 m3_fun_sym(const M3 &s, int fn) {   // fn 0: sqrt, 1: inverse sqrt  (of a symmetric PSD matrix)
+    M3 v;
+    double lam[3];
+    m3_eig_sym(s, v, lam);
+    M3 r;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k < 3; ++k) {
+                const double f = fn == 0 ? sqrt(lam[k]) : 1.0 / sqrt(lam[k]);
+                acc = fma(v.a[i][k] * f, v.a[j][k], acc);
+            }
+            r.a[i][j] = acc;
+        }
+    return r;
+}
+
+__device__ inline M3 m3_chol(const M3 &s) {   // lower L with L L^T = s
+    M3 l;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) l.a[i][j] = 0.0;
+    l.a[0][0] = sqrt(s.a[0][0]);
+    l.a[1][0] = s.a[1][0] / l.a[0][0];
+    l.a[2][0] = s.a[2][0] / l.a[0][0];
+    l.a[1][1] = sqrt(s.a[1][1] - l.a[1][0] * l.a[1][0]);
+    l.a[2][1] = (s.a[2][1] - l.a[2][0] * l.a[1][0]) / l.a[1][1];
+    l.a[2][2] = sqrt(s.a[2][2] - l.a[2][0] * l.a[2][0] - l.a[2][1] * l.a[2][1]);
+    return l;
+}
+
+__device__ inline M3 m3_inv_lower(const M3 &l) {
+    M3 r;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) r.a[i][j] = 0.0;
+    r.a[0][0] = 1.0 / l.a[0][0];
+    r.a[1][1] = 1.0 / l.a[1][1];
+    r.a[2][2] = 1.0 / l.a[2][2];
+    r.a[1][0] = -l.a[1][0] * r.a[0][0] * r.a[1][1];
+    r.a[2][1] = -l.a[2][1] * r.a[1][1] * r.a[2][2];
+    r.a[2][0] = -(l.a[2][0] * r.a[0][0] + l.a[2][1] * r.a[1][0]) * r.a[2][2];
+    return r;
+}
+
+__global__ void mk_coef_kernel(const double *__restrict__ stats_t, const double *__restrict__ stats_r, int mode, int batch,
+                               double *__restrict__ coef) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const double *st = stats_t + (size_t)b * CT_RGB_STATS_STRIDE, *sr = stats_r + (size_t)b * CT_RGB_STATS_STRIDE;
+    M3 ct_, cr;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) { ct_.a[i][j] = st[3 + 3 * i + j]; cr.a[i][j] = sr[3 + 3 * i + j]; }
+    M3 T;
+    if (mode == 0) {            // A = sqrtm(St); T = A^-1 sqrtm(A Sr A) A^-1          (linear.py:116-118)
+        const M3 A = m3_fun_sym(ct_, 0), Ai = m3_fun_sym(ct_, 1);
+        M3 mid = m3_mul(m3_mul(A, cr), A);
+        for (int i = 0; i < 3; ++i)   // symmetrise the rounding residue before the eigen-decomposition
+            for (int j = i + 1; j < 3; ++j) { const double h = 0.5 * (mid.a[i][j] + mid.a[j][i]); mid.a[i][j] = h; mid.a[j][i] = h; }
+        T = m3_mul(m3_mul(Ai, m3_fun_sym(mid, 0)), Ai);
+    } else if (mode == 1) {     // T = sqrtm(Sr) sqrtm(St)^-1                         (linear.py:112-115)
+        T = m3_mul(m3_fun_sym(cr, 0), m3_fun_sym(ct_, 1));
+    } else {                    // T = chol(Sr) chol(St)^-1                           (linear.py:108-111)
+        T = m3_mul(m3_chol(cr), m3_inv_lower(m3_chol(ct_)));
+    }
+    double *o = coef + (size_t)b * 16;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) o[3 * i + j] = T.a[i][j];
+    for (int i = 0; i < 3; ++i) { o[9 + i] = st[i]; o[12 + i] = sr[i]; }
+    o[15] = 0.0;
+}
+
+// -------------------------------------------------------------------------------------------
 // host-side launchers
 // -------------------------------------------------------------------------------------------
 template <typename T>
@@ -473,6 +593,15 @@ int ct_rgb_meancov_f32(const float *rgb, int64_t n_pixels, int n_images, double 
 int ct_rgb_meancov_f64(const double *rgb, int64_t n_pixels, int n_images, double *stats, void *ws, size_t ws_bytes,
                        void *stream) {
     return ct::rgb_meancov_impl<double>(rgb, n_pixels, n_images, stats, ws, ws_bytes, stream);
+}
+
+int ct_mk_coef_f64(const double *stats_t, const double *stats_r, int decomposition, int batch, double *coef, void *stream) {
+    if (!stats_t || !stats_r || !coef || batch < 0 || decomposition < 0 || decomposition > 2) return CT_E_BADARG;
+    if (batch == 0) return CT_OK;
+    hipLaunchKernelGGL(ct::mk_coef_kernel, dim3((batch + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats_t, stats_r, decomposition,
+                       batch, coef);
+    CT_CHECK_LAUNCH();
+    return CT_OK;
 }
 
 int ct_affine3x3_f32_f64(const float *in, const double *coef, double *out, int64_t n_pixels, int batch, void *stream) {

@@ -40,6 +40,7 @@ SIGNATURES = {
     "ct_reinhard_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
     "ct_rgb_meancov_f32": (_c_int, [_c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
     "ct_rgb_meancov_f64": (_c_int, [_c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
+    "ct_mk_coef_f64": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_p, _c_p]),
     "ct_affine3x3_f32_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_p]),
     "ct_affine3x3_f64_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_p]),
     "ct_affine3x3_f32_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_p]),
@@ -199,6 +200,16 @@ def reinhard(target, reference, out=None, stats_out=None):
     sp = _ptr(stats_out) if stats_out is not None else ctypes.c_void_p(0)
     check(fn(_ptr(x), _ptr(r), _ptr(out), n, B, sp, _ptr(ws), ws.numel(), _stream()))
     return out.view(target.shape)
+
+
+def mk_coef(stats_t, stats_r, decomposition="MK"):
+    """On-device 3x3 algebra of MK (methods/linear.py:108-118): rgb_meancov records -> affine3x3 coefficient records."""
+    mode = {"MK": 0, "sqrt": 1, "cholesky": 2}[decomposition]
+    _require_cuda(stats_t, stats_r)
+    b = stats_t.shape[0]
+    coef = torch.empty((b, 16), dtype=torch.float64, device=stats_t.device)
+    check(lib().ct_mk_coef_f64(_ptr(stats_t), _ptr(stats_r), mode, b, _ptr(coef), _stream()))
+    return coef
 
 
 def affine3x3(img, coef, out_dtype=torch.float64, out=None):

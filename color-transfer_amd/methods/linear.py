@@ -137,9 +137,16 @@ def color_transfer_in_correlated_color_space_cuda(target, reference, out_dtype=t
     return _affine(target, T.T, mt, mr, out_dtype)     # reference: (x - mu) @ T.T + mu_r
 
 
-def monge_kantorovitch_color_transfer_cuda(target, reference, decomposition="MK", out_dtype=torch.float64):
+def monge_kantorovitch_color_transfer_cuda(target, reference, decomposition="MK", out_dtype=torch.float64,
+                                           host_algebra=False, out=None):
+    """Device-resident MK transfer, [H,W,3] or [B,H,W,3] tensors.  By default the 3x3 algebra also runs on the device
+    (ct_mk_coef_f64: no host synchronisation, batches of pairs per call); host_algebra=True reproduces the
+    reference's scipy/numpy calls literally (single pair)."""
     if decomposition not in ("cholesky", "sqrt", "MK"):
         raise ValueError("Unknown decomposition, use either 'cholesky', 'sqrt', or 'MK'")
+    if not host_algebra:
+        coef = ct_hip.mk_coef(ct_hip.rgb_meancov(target), ct_hip.rgb_meancov(reference), decomposition)
+        return ct_hip.affine3x3(target, coef, out_dtype=out_dtype, out=out)
     mt, ct_, mr, cr = _host_moments(target, reference)
     T = mk_matrix(ct_, cr, decomposition)
     return _affine(target, T, mt, mr, out_dtype)       # reference: (x - mu) @ T + mu_r
@@ -163,5 +170,6 @@ def monge_kantorovitch_color_transfer(target, reference, decomposition="MK"):
     target = _as_float(target)
     reference = _as_float(reference)
     shape = target.shape
-    out = monge_kantorovitch_color_transfer_cuda(_to_device(target), _to_device(reference), decomposition)
+    # the numpy drop-in keeps the reference's own LAPACK/scipy calls for the 3x3 algebra
+    out = monge_kantorovitch_color_transfer_cuda(_to_device(target), _to_device(reference), decomposition, host_algebra=True)
     return out.cpu().numpy().reshape(shape)

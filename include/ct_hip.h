@@ -90,6 +90,14 @@ int ct_rgb_meancov_f32(const float *rgb, int64_t n_pixels, int n_images, double 
 int ct_rgb_meancov_f64(const double *rgb, int64_t n_pixels, int n_images, double *stats,
                        void *ws, size_t ws_bytes, void *stream);
 
+/* ---- A4 (sync-free): the 3x3 algebra of monge_kantorovitch_color_transfer on the device (methods/linear.py:108-118) ----
+ * stats_t / stats_r: records of ct_rgb_meancov; decomposition 0 "MK", 1 "sqrt", 2 "cholesky"; writes the 16-double coef
+ * records ct_affine3x3_* consumes (T is applied as x @ T).  float64 Jacobi eigen-decomposition: the SPD matrix square root
+ * is unique, so it equals scipy.linalg.sqrtm to rounding.  (Xiao's SVD-based matrix depends on LAPACK's sign
+ * convention and is computed on the host.)                                                                            */
+int ct_mk_coef_f64(const double *stats_t, const double *stats_r, int decomposition, int batch, double *coef,
+                   void *stream);
+
 /* ---- A5: (x - mu_t) @ A + mu_r   (methods/linear.py:80,122) ----
  * coef: device, 16 doubles per image: A[9] row-major such that out_j = sum_i (x_i-mu_t_i)*A[i][j]
  * (pass T for MK, T.T for Xiao), mu_t[3], mu_r[3], pad.  No clipping (the reference does
