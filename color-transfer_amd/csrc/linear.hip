@@ -277,7 +277,39 @@ __global__ __launch_bounds__(kBlock) void affine3x3_kernel(const TI *__restrict_
     };
     const int64_t n_chunks = n_pixels >> 2;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t ch = (int64_t)blockIdx.x * kBlock + threadIdx.x; ch < n_chunks; ch += stride) {
+    constexpr bool kF32IO = sizeof(TI) == 4 && sizeof(TO) == 4;
+    __shared__ float xpose[kF32IO ? kBlock * 12 : 1];   // per-wave 3 KiB transpose buffers (float I/O only)
+    for (int64_t ch0 = (int64_t)blockIdx.x * kBlock; ch0 < n_chunks; ch0 += stride) {
+        const int64_t ch = ch0 + threadIdx.x;
+        const int64_t wave_c0 = ch0 + (threadIdx.x & ~63);
+        const bool full_wave = wave_c0 + 64 <= n_chunks;          // wave-uniform
+        if (kF32IO && vin && vout && full_wave) {
+            // fully coalesced 16-byte global accesses (lane i <-> base + 16 i, three times per wave); the HWC de-interleave
+            // into "4 whole pixels per lane" and back happens in a per-wave LDS buffer (conflict-free b128 accesses)
+            const int lane = threadIdx.x & 63;
+            float *lw = xpose + (threadIdx.x >> 6) * (64 * 12);
+            const float4 *g = reinterpret_cast<const float4 *>(p + wave_c0 * 12);
+            float4 *l4 = reinterpret_cast<float4 *>(lw);
+            l4[lane] = g[lane]; l4[64 + lane] = g[64 + lane]; l4[128 + lane] = g[128 + lane];
+            __builtin_amdgcn_wave_barrier();
+            const float4 *r4 = reinterpret_cast<const float4 *>(lw + lane * 12);
+            const float4 a0 = r4[0], a1 = r4[1], a2 = r4[2];
+            const float vi[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
+            TO w[12];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) px((double)vi[3 * q], (double)vi[3 * q + 1], (double)vi[3 * q + 2], w[3 * q], w[3 * q + 1], w[3 * q + 2]);
+            __builtin_amdgcn_wave_barrier();
+            float4 *w4 = reinterpret_cast<float4 *>(lw + lane * 12);
+            w4[0] = make_float4((float)w[0], (float)w[1], (float)w[2], (float)w[3]);
+            w4[1] = make_float4((float)w[4], (float)w[5], (float)w[6], (float)w[7]);
+            w4[2] = make_float4((float)w[8], (float)w[9], (float)w[10], (float)w[11]);
+            __builtin_amdgcn_wave_barrier();
+            float4 *go = reinterpret_cast<float4 *>(reinterpret_cast<float *>(o) + wave_c0 * 12);
+            go[lane] = l4[lane]; go[64 + lane] = l4[64 + lane]; go[128 + lane] = l4[128 + lane];
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
+        if (ch >= n_chunks) continue;
         double v[12];
         TO w[12];
         load12<TI>(p + ch * 12, vin, v);
@@ -315,9 +347,10 @@ __device__ inline M3 m3_mul(const M3 &x, const M3 &y) {
 __device__ inline void m3_eig_sym(M3 s, M3 &v, double (&lam)[3]) {   // s = v diag(lam) v^T, cyclic Jacobi
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) v.a[i][j] = (i == j) ? 1.0 : 0.0;
+    const double tiny = 1e-32 * (fabs(s.a[0][0]) + fabs(s.a[1][1]) + fabs(s.a[2][2]));
     for (int sweep = 0; sweep < 12; ++sweep) {
         const double off = fabs(s.a[0][1]) + fabs(s.a[0][2]) + fabs(s.a[1][2]);
-        if (off == 0.0) break;
+        if (off <= tiny) break;          // quadratic convergence: 4-5 sweeps for a 3x3
         for (int p = 0; p < 2; ++p)
             for (int q = p + 1; q < 3; ++q) {
                 const double apq = s.a[p][q];
@@ -345,10 +378,7 @@ __device__ inline void m3_eig_sym(M3 s, M3 &v, double (&lam)[3]) {   // s = v di
     for (int i = 0; i < 3; ++i) lam[i] = s.a[i][i];
 }
 
-__device__ inline M3 m3_fun_sym(const M3 &s, int fn) {   // fn 0: sqrt, 1: inverse sqrt  (of a symmetric PSD matrix)
-    M3 v;
-    double lam[3];
-    m3_eig_sym(s, v, lam);
+__device__ inline M3 m3_from_eig(const M3 &v, const double (&lam)[3], int fn) {   // v f(diag(lam)) v^T
     M3 r;
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) {
@@ -360,6 +390,13 @@ __device__ inline M3 m3_fun_sym(const M3 &s, int fn) {   // fn 0: sqrt, 1: inver
             r.a[i][j] = acc;
         }
     return r;
+}
+
+__device__ inline M3 m3_fun_sym(const M3 &s, int fn) {   // fn 0: sqrt, 1: inverse sqrt  (of a symmetric PSD matrix)
+    M3 v;
+    double lam[3];
+    m3_eig_sym(s, v, lam);
+    return m3_from_eig(v, lam, fn);
 }
 
 __device__ inline M3 m3_chol(const M3 &s) {   // lower L with L L^T = s
@@ -398,7 +435,10 @@ __global__ void mk_coef_kernel(const double *__restrict__ stats_t, const double 
         for (int j = 0; j < 3; ++j) { ct_.a[i][j] = st[3 + 3 * i + j]; cr.a[i][j] = sr[3 + 3 * i + j]; }
     M3 T;
     if (mode == 0) {            // A = sqrtm(St); T = A^-1 sqrtm(A Sr A) A^-1          (linear.py:116-118)
-        const M3 A = m3_fun_sym(ct_, 0), Ai = m3_fun_sym(ct_, 1);
+        M3 vt;
+        double lt[3];
+        m3_eig_sym(ct_, vt, lt);
+        const M3 A = m3_from_eig(vt, lt, 0), Ai = m3_from_eig(vt, lt, 1);
         M3 mid = m3_mul(m3_mul(A, cr), A);
         for (int i = 0; i < 3; ++i)   // symmetrise the rounding residue before the eigen-decomposition
             for (int j = i + 1; j < 3; ++j) { const double h = 0.5 * (mid.a[i][j] + mid.a[j][i]); mid.a[i][j] = h; mid.a[j][i] = h; }
@@ -511,6 +551,29 @@ static int affine_impl(const TI *in, const double *coef, TO *out, int64_t n_pixe
     return CT_OK;
 }
 
+// a3 fused: moments of all 2*batch images in one sweep, finishing kernel, 3x3 algebra, affine apply -- no host sync
+template <typename T, typename TO>
+static int mk_impl(const T *target, const T *reference, TO *out, int64_t n_pixels, int batch, int decomposition, void *ws,
+                   size_t ws_bytes, void *stream) {
+    int rc = check_image_args(target, n_pixels, batch);
+    if (rc) return rc;
+    if ((rc = check_image_args(reference, n_pixels, batch))) return rc;
+    if ((rc = check_image_args(out, n_pixels, batch))) return rc;
+    if (decomposition < 0 || decomposition > 2) return CT_E_BADARG;
+    if ((rc = check_ws(ws, ws_bytes, 2 * batch))) return rc;
+    if (batch == 0 || n_pixels == 0) return CT_OK;
+    const WsLayout l = ws_carve(ws, 2 * batch);
+    hipStream_t s = (hipStream_t)stream;
+    rc = launch_moments<T, false>(target, reference, batch, 2 * batch, n_pixels, l, l.stats, s);
+    if (rc) return rc;
+    // coefficient records live behind the stats records (the workspace reserves CT_RGB_STATS_STRIDE doubles per image)
+    double *coef = l.partials;   // the partial sums are dead once the finishing kernel has run
+    hipLaunchKernelGGL(mk_coef_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, (const double *)l.stats,
+                       (const double *)(l.stats + (size_t)batch * CT_RGB_STATS_STRIDE), decomposition, batch, coef);
+    CT_CHECK_LAUNCH();
+    return affine_impl<T, TO>(target, coef, out, n_pixels, batch, stream);
+}
+
 }  // namespace ct
 
 // -------------------------------------------------------------------------------------------
@@ -593,6 +656,19 @@ int ct_rgb_meancov_f32(const float *rgb, int64_t n_pixels, int n_images, double 
 int ct_rgb_meancov_f64(const double *rgb, int64_t n_pixels, int n_images, double *stats, void *ws, size_t ws_bytes,
                        void *stream) {
     return ct::rgb_meancov_impl<double>(rgb, n_pixels, n_images, stats, ws, ws_bytes, stream);
+}
+
+int ct_mk_f32_f32(const float *target, const float *reference, float *out, int64_t n_pixels, int batch, int decomposition, void *ws,
+                  size_t ws_bytes, void *stream) {
+    return ct::mk_impl<float, float>(target, reference, out, n_pixels, batch, decomposition, ws, ws_bytes, stream);
+}
+int ct_mk_f32_f64(const float *target, const float *reference, double *out, int64_t n_pixels, int batch, int decomposition, void *ws,
+                  size_t ws_bytes, void *stream) {
+    return ct::mk_impl<float, double>(target, reference, out, n_pixels, batch, decomposition, ws, ws_bytes, stream);
+}
+int ct_mk_f64_f64(const double *target, const double *reference, double *out, int64_t n_pixels, int batch, int decomposition, void *ws,
+                  size_t ws_bytes, void *stream) {
+    return ct::mk_impl<double, double>(target, reference, out, n_pixels, batch, decomposition, ws, ws_bytes, stream);
 }
 
 int ct_mk_coef_f64(const double *stats_t, const double *stats_r, int decomposition, int batch, double *coef, void *stream) {

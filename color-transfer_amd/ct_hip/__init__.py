@@ -40,6 +40,9 @@ SIGNATURES = {
     "ct_reinhard_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
     "ct_rgb_meancov_f32": (_c_int, [_c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
     "ct_rgb_meancov_f64": (_c_int, [_c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
+    "ct_mk_f32_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_int, _c_p, _c_sz, _c_p]),
+    "ct_mk_f32_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_int, _c_p, _c_sz, _c_p]),
+    "ct_mk_f64_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_int, _c_p, _c_sz, _c_p]),
     "ct_mk_coef_f64": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_p, _c_p]),
     "ct_affine3x3_f32_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_p]),
     "ct_affine3x3_f64_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_p]),
@@ -199,6 +202,25 @@ def reinhard(target, reference, out=None, stats_out=None):
             raise CtHipError("stats_out must be float64 with >= 2*B*8 elements")
     sp = _ptr(stats_out) if stats_out is not None else ctypes.c_void_p(0)
     check(fn(_ptr(x), _ptr(r), _ptr(out), n, B, sp, _ptr(ws), ws.numel(), _stream()))
+    return out.view(target.shape)
+
+
+def mk(target, reference, decomposition="MK", out_dtype=torch.float64, out=None):
+    """methods.linear.monge_kantorovitch_color_transfer on device tensors, B pairs per call, no host sync (ct_mk_*)."""
+    x, _ = _as_batch(target)
+    r, _ = _as_batch(reference)
+    _require_cuda(x, r)
+    if x.shape != r.shape or x.dtype != r.dtype:
+        raise CtHipError("fused mk needs equal shapes/dtypes")
+    B, n = x.shape[0], x.shape[1] * x.shape[2]
+    if out is None:
+        out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    name = "ct_mk_%s_%s" % (_suffix(x), _suffix(out))
+    if name not in SIGNATURES:
+        raise CtHipError("no kernel for %s" % name)
+    ws = workspace(CT_WS_REINHARD, n, B, x.device)
+    mode = {"MK": 0, "sqrt": 1, "cholesky": 2}[decomposition]
+    check(getattr(lib(), name)(_ptr(x), _ptr(r), _ptr(out), n, B, mode, _ptr(ws), ws.numel(), _stream()))
     return out.view(target.shape)
 
 

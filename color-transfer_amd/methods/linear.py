@@ -145,6 +145,8 @@ def monge_kantorovitch_color_transfer_cuda(target, reference, decomposition="MK"
     if decomposition not in ("cholesky", "sqrt", "MK"):
         raise ValueError("Unknown decomposition, use either 'cholesky', 'sqrt', or 'MK'")
     if not host_algebra:
+        if target.shape == reference.shape:
+            return ct_hip.mk(target, reference, decomposition, out_dtype=out_dtype, out=out)
         coef = ct_hip.mk_coef(ct_hip.rgb_meancov(target), ct_hip.rgb_meancov(reference), decomposition)
         return ct_hip.affine3x3(target, coef, out_dtype=out_dtype, out=out)
     mt, ct_, mr, cr = _host_moments(target, reference)

@@ -98,6 +98,16 @@ int ct_rgb_meancov_f64(const double *rgb, int64_t n_pixels, int n_images, double
 int ct_mk_coef_f64(const double *stats_t, const double *stats_r, int decomposition, int batch, double *coef,
                    void *stream);
 
+/* ---- a3 fused: methods.linear.monge_kantorovitch_color_transfer (methods/linear.py:85-124), batch pairs per call,
+ * everything on the device (moments of all 2*batch images in one sweep, finishing kernel, ct_mk_coef, affine apply).
+ * ws: ct_workspace_bytes(CT_WS_REINHARD, n_pixels, batch).  Output unclipped like the reference.                      */
+int ct_mk_f32_f32(const float *target, const float *reference, float *out, int64_t n_pixels, int batch,
+                  int decomposition, void *ws, size_t ws_bytes, void *stream);
+int ct_mk_f32_f64(const float *target, const float *reference, double *out, int64_t n_pixels, int batch,
+                  int decomposition, void *ws, size_t ws_bytes, void *stream);
+int ct_mk_f64_f64(const double *target, const double *reference, double *out, int64_t n_pixels, int batch,
+                  int decomposition, void *ws, size_t ws_bytes, void *stream);
+
 /* ---- A5: (x - mu_t) @ A + mu_r   (methods/linear.py:80,122) ----
  * coef: device, 16 doubles per image: A[9] row-major such that out_j = sum_i (x_i-mu_t_i)*A[i][j]
  * (pass T for MK, T.T for Xiao), mu_t[3], mu_r[3], pad.  No clipping (the reference does
