@@ -551,6 +551,44 @@ static int affine_impl(const TI *in, const double *coef, TO *out, int64_t n_pixe
     return CT_OK;
 }
 
+// -------------------------------------------------------------------------------------------
+// Per-frame PSNR (the metric Runner.test_step logs, methods/__init__.py:32,37; piq.psnr semantics: inputs
+// clamped by the caller, data_range 1, mean squared error over all elements of a frame, 10 log10(1/mse)).
+// Deterministic: float64 partial sums per workgroup, fixed-order finish.  grid = (G, batch).
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void sqerr_partial_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                               int64_t n, double *__restrict__ partials) {
+    __shared__ double lds[4];
+    const float *pa = a + (size_t)blockIdx.y * n, *pb = b + (size_t)blockIdx.y * n;
+    double s[1] = {0.0};
+    const bool vec = ((reinterpret_cast<uintptr_t>(pa) | reinterpret_cast<uintptr_t>(pb)) & 15) == 0;
+    const int64_t n4 = vec ? (n >> 2) : 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+        const float4 x = reinterpret_cast<const float4 *>(pa)[i], y = reinterpret_cast<const float4 *>(pb)[i];
+        const double d0 = (double)x.x - y.x, d1 = (double)x.y - y.y, d2 = (double)x.z - y.z, d3 = (double)x.w - y.w;
+        s[0] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const double d = (double)pa[i] - pb[i];
+        s[0] += d * d;
+    }
+    block_sum<1>(s, lds);
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.y * kMaxBlocksPerImage + blockIdx.x] = s[0];
+}
+
+__global__ __launch_bounds__(kBlock) void psnr_finish_kernel(const double *__restrict__ partials, int n_blocks, int64_t n,
+                                                             double *__restrict__ out) {
+    __shared__ double lds[4];
+    double s[1] = {0.0};
+    for (int i = threadIdx.x; i < n_blocks; i += kBlock) s[0] += partials[(size_t)blockIdx.x * kMaxBlocksPerImage + i];
+    block_sum<1>(s, lds);
+    if (threadIdx.x == 0) {
+        const double mse = s[0] / (double)n;
+        out[blockIdx.x * 2] = mse;
+        out[blockIdx.x * 2 + 1] = 10.0 * log10(1.0 / (mse > 1e-300 ? mse : 1e-300));
+    }
+}
+
 // a3 fused: moments of all 2*batch images in one sweep, finishing kernel, 3x3 algebra, affine apply -- no host sync
 template <typename T, typename TO>
 static int mk_impl(const T *target, const T *reference, TO *out, int64_t n_pixels, int batch, int decomposition, void *ws,
@@ -669,6 +707,18 @@ int ct_mk_f32_f64(const float *target, const float *reference, double *out, int6
 int ct_mk_f64_f64(const double *target, const double *reference, double *out, int64_t n_pixels, int batch, int decomposition, void *ws,
                   size_t ws_bytes, void *stream) {
     return ct::mk_impl<double, double>(target, reference, out, n_pixels, batch, decomposition, ws, ws_bytes, stream);
+}
+
+int ct_frame_psnr_f32(const float *a, const float *b, int64_t n_elems, int batch, double *out, void *ws, size_t ws_bytes, void *stream) {
+    if (!a || !b || !out || n_elems < 1 || batch < 0) return CT_E_BADARG;
+    if (!ws || ws_bytes < (size_t)batch * ct::kMaxBlocksPerImage * sizeof(double)) return CT_E_WORKSPACE;
+    if (batch == 0) return CT_OK;
+    const int G = ct::blocks_per_image(n_elems >> 2, batch);
+    hipLaunchKernelGGL(ct::sqerr_partial_kernel, dim3(G, batch), dim3(ct::kBlock), 0, (hipStream_t)stream, a, b, n_elems, (double *)ws);
+    CT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ct::psnr_finish_kernel, dim3(batch), dim3(ct::kBlock), 0, (hipStream_t)stream, (const double *)ws, G, n_elems, out);
+    CT_CHECK_LAUNCH();
+    return CT_OK;
 }
 
 int ct_mk_coef_f64(const double *stats_t, const double *stats_r, int decomposition, int batch, double *coef, void *stream) {

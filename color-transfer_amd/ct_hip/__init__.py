@@ -43,6 +43,7 @@ SIGNATURES = {
     "ct_mk_f32_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_int, _c_p, _c_sz, _c_p]),
     "ct_mk_f32_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_int, _c_p, _c_sz, _c_p]),
     "ct_mk_f64_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_int, _c_p, _c_sz, _c_p]),
+    "ct_frame_psnr_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
     "ct_mk_coef_f64": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_p, _c_p]),
     "ct_affine3x3_f32_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_p]),
     "ct_affine3x3_f64_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_p]),
@@ -222,6 +223,19 @@ def mk(target, reference, decomposition="MK", out_dtype=torch.float64, out=None)
     mode = {"MK": 0, "sqrt": 1, "cholesky": 2}[decomposition]
     check(getattr(lib(), name)(_ptr(x), _ptr(r), _ptr(out), n, B, mode, _ptr(ws), ws.numel(), _stream()))
     return out.view(target.shape)
+
+
+def frame_psnr(a, b):
+    """Per-frame (mse, PSNR) of two float32 batches [B, ...] with data range 1 -> float64 [B, 2] (methods/__init__.py:32)."""
+    _require_cuda(a, b)
+    if a.shape != b.shape or a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise CtHipError("frame_psnr needs two float32 tensors of one shape")
+    B = a.shape[0]
+    n = a.numel() // max(B, 1)
+    out = torch.empty((B, 2), dtype=torch.float64, device=a.device)
+    ws = workspace(CT_WS_LAB_STATS, n, B, a.device)
+    check(lib().ct_frame_psnr_f32(_ptr(a), _ptr(b), n, B, _ptr(out), _ptr(ws), ws.numel(), _stream()))
+    return out
 
 
 def mk_coef(stats_t, stats_r, decomposition="MK"):

@@ -14,7 +14,11 @@ import torch
 
 
 def psnr(x, y, data_range=1.0):
-    """Peak signal-to-noise ratio per sample, [B] (piq.psnr semantics: mean over C,H,W, then -10 log10)."""
+    """Peak signal-to-noise ratio per sample, [B] (piq.psnr semantics: mean over C,H,W, then 10 log10(1/mse)); the
+    reduction runs in ct_frame_psnr_f32 (deterministic float64 sums) when the tensors live on the GPU."""
+    if x.is_cuda and data_range == 1.0:
+        import ct_hip
+        return ct_hip.frame_psnr(x.float().contiguous(), y.float().contiguous())[:, 1]
     mse = ((x.double() - y.double()) ** 2).flatten(1).mean(dim=1)
     return 10.0 * torch.log10(data_range ** 2 / mse.clamp_min(1e-300))
 

@@ -119,6 +119,12 @@ int ct_affine3x3_f64_f64(const double *in, const double *coef, double *out, int6
 int ct_affine3x3_f32_f32(const float *in, const double *coef, float *out, int64_t n_pixels,
                          int batch, void *stream);
 
+/* ---- per-frame metric (first step): PSNR as Runner.test_step logs it (methods/__init__.py:32,37) ----
+ * a, b: [batch][n_elems] float32 (any layout, same for both); out[i] = {mse, 10 log10(1/mse)} (data range 1).
+ * Deterministic float64 reduction.  ws: batch * 1024 doubles (ct_workspace_bytes(CT_WS_LAB_STATS, ., batch) suffices). */
+int ct_frame_psnr_f32(const float *a, const float *b, int64_t n_elems, int batch, double *out, void *ws,
+                      size_t ws_bytes, void *stream);
+
 /* ---- a4: methods.iterative.iterative_distribution_transfer (methods/iterative.py:8-59) ----
  * Per iteration: projection on the rotated axes (float64, fma chain), exact lo/hi, 2x3 histograms
  * with numpy's bin rule (LDS-binned integer atomics), cumulative LUT, np.interp apply with the

@@ -45,3 +45,15 @@ def test_cli_dcmcs3di(capsys):
     table = cli.main(["test", "--config", os.path.join(CFG, "dcmcs3di.yaml"), "--model.extraction_layers", "2",
                       "--model.transfer_layers", "1", "--data.n_frames", "2", "--data.height", "32", "--data.width", "64"])
     assert table.shape == (2, 1) and torch.isfinite(table).all()
+
+
+def test_frame_psnr_kernel():
+    import ct_hip
+    gen = torch.Generator().manual_seed(0)
+    a = torch.rand(3, 3, 37, 53, generator=gen)
+    b = (a + 0.05 * torch.randn(3, 3, 37, 53, generator=gen)).clamp(0, 1)
+    out = ct_hip.frame_psnr(a.cuda(), b.cuda()).cpu()
+    mse = ((a.double() - b.double()) ** 2).flatten(1).mean(1)
+    assert torch.allclose(out[:, 0], mse, rtol=1e-12, atol=0)
+    assert torch.allclose(out[:, 1], 10 * torch.log10(1 / mse), rtol=1e-12, atol=0)
+    assert torch.equal(out, ct_hip.frame_psnr(a.cuda(), b.cuda()).cpu())          # deterministic
