@@ -262,26 +262,80 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
                                                                const float *__restrict__ v, const int *__restrict__ region,
                                                                float *__restrict__ out, float *__restrict__ stats, int L,
                                                                float scale) {
-    constexpr int CH = C / 2;            // channels per lane half
-    constexpr int NVT = CV >= 32 ? CV / 32 : 1;   // 32-channel value tiles on the MFMA path
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nl = lane & 31, hl = lane >> 5;
+    constexpr int CH = C / 2;                       // channels per lane half
+    constexpr int NVT = CV >= 32 ? CV / 32 : 1;     // 32-channel value tiles on the MFMA path
+    constexpr int KLD = C + 4;                      // padded LDS rows: the 16-lane column reads (b128) are conflict free
+    constexpr int VLD = CV >= 32 ? CV + 4 : 4;
+    constexpr int KV4 = (32 * C / 4) / 256;         // float4 per thread of one K tile (4 / 2)
+    constexpr int VV4 = CV >= 32 ? (32 * CV / 4) / 256 : 1;   // V tile (4 / 3), or the 16 float4 of a 2-channel tile
+    // The 4 waves of a workgroup attend 4 x 32 queries of the SAME batch item to the same keys: every 32-key tile
+    // of K and V is fetched once per workgroup with 16-byte loads (next tile in flight in registers while the current
+    // one is multiplied), staged in LDS, and read from there as MFMA operands.
+    __shared__ float Ks[32 * KLD];
+    __shared__ float Vs[32 * VLD];
+    __shared__ int Rs[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, hl = lane >> 5;
     const int b = blockIdx.y;
     const int q0 = (blockIdx.x * 4 + wave) * 32;
-    if (q0 >= L) return;
     const size_t tb = (size_t)b * L;
     const int qi = q0 + nl;
     const bool qlive = qi < L;
+    const int qclamp = qlive ? qi : L - 1;
     // B operand of S^T = K Q^T : lane (query nl, half hl) holds q[query][hl*C/2 + p], p < C/2
     float qb[CH];
     {
-        const float *qp = q + (tb + (qlive ? qi : L - 1)) * C + hl * CH;
+        const float *qp = q + (tb + qclamp) * C + hl * CH;
 #pragma unroll
         for (int i = 0; i < CH / 4; ++i) {
             const float4 t = *reinterpret_cast<const float4 *>(qp + 4 * i);
             qb[4 * i] = t.x * scale; qb[4 * i + 1] = t.y * scale; qb[4 * i + 2] = t.z * scale; qb[4 * i + 3] = t.w * scale;
         }
     }
-    const int qreg = region ? region[tb + (qlive ? qi : L - 1)] : 0;
+    const int qreg = region ? region[tb + qclamp] : 0;
+
+    float4 kpre[KV4], vpre[VV4];
+    int rpre = 0;
+    auto fetch = [&](int j0) {
+#pragma unroll
+        for (int i = 0; i < KV4; ++i) {
+            const int f = tid + i * 256, key = f / (C / 4), c4 = f - key * (C / 4);
+            kpre[i] = (j0 + key < L) ? *reinterpret_cast<const float4 *>(k + (tb + j0 + key) * C + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (CV >= 32) {
+#pragma unroll
+            for (int i = 0; i < VV4; ++i) {
+                const int f = tid + i * 256, key = f / (CV / 4), c4 = f - key * (CV / 4);
+                vpre[i] = (j0 + key < L) ? *reinterpret_cast<const float4 *>(v + (tb + j0 + key) * CV + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else if (CV == 2) {
+            if (tid < 16) {   // 32 keys x 2 channels = 16 float4
+                const int key = 2 * tid;
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (j0 + key + 1 < L) t = *reinterpret_cast<const float4 *>(v + (tb + j0 + key) * 2);
+                else if (j0 + key < L) { const float2 u = *reinterpret_cast<const float2 *>(v + (tb + j0 + key) * 2); t.x = u.x; t.y = u.y; }
+                vpre[0] = t;
+            }
+        }
+        if (region && tid < 32) rpre = (j0 + tid < L) ? region[tb + j0 + tid] : 0;
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < KV4; ++i) {
+            const int f = tid + i * 256, key = f / (C / 4), c4 = f - key * (C / 4);
+            *reinterpret_cast<float4 *>(Ks + key * KLD + 4 * c4) = kpre[i];
+        }
+        if (CV >= 32) {
+#pragma unroll
+            for (int i = 0; i < VV4; ++i) {
+                const int f = tid + i * 256, key = f / (CV / 4), c4 = f - key * (CV / 4);
+                *reinterpret_cast<float4 *>(Vs + key * VLD + 4 * c4) = vpre[i];
+            }
+        } else if (CV == 2) {
+            if (tid < 16) *reinterpret_cast<float4 *>(Vs + 4 * tid) = vpre[0];   // Vs[key*2 + ch]
+        }
+        if (region && tid < 32) Rs[tid] = rpre;
+    };
+
     float m_run = -INFINITY, l_run = 0.f;
     f32x16g o[NVT];
     float o2x = 0.f, o2y = 0.f;
@@ -291,13 +345,17 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
     }
+    fetch(0);
+    stage();
+    __syncthreads();
     for (int j0 = 0; j0 < L; j0 += 32) {
-        // ---- S^T tile: A = K rows (key nl), B = Q ----
-        const int kj = j0 + nl;
-        const float *kp = k + (tb + (kj < L ? kj : L - 1)) * C + hl * CH;
+        const bool more = j0 + 32 < L;
+        if (more) fetch(j0 + 32);
+        // ---- S^T tile: A = K rows (key nl) from LDS, B = Q ----
         f32x16g s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        const float *kp = Ks + nl * KLD + hl * CH;
 #pragma unroll
         for (int i = 0; i < CH / 4; ++i) {
             const float4 t = *reinterpret_cast<const float4 *>(kp + 4 * i);
@@ -310,10 +368,10 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
         float mx = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+            const int kl = (r & 3) + 8 * (r >> 2) + 4 * hl;
             float sv = s[r];
-            if (region) sv += (region[tb + (key < L ? key : L - 1)] != qreg) ? -100.0f : 0.0f;
-            sv = key < L ? sv : -INFINITY;
+            if (region) sv += (Rs[kl] != qreg) ? -100.0f : 0.0f;
+            sv = (j0 + kl < L) ? sv : -INFINITY;
             s[r] = sv;
             mx = fmaxf(mx, sv);
         }
@@ -336,11 +394,10 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[j][r] *= corr;
             // O^T[c][query] += sum_key V[key][c] P[key][query]: k-step r pairs the keys held by the two lane halves
-            // in register r (keys kk and kk+4); A = V[key][channel nl of each 32-channel tile]
+            // in register r (keys kk and kk+4); A = V[key][channel nl of each 32-channel tile] from LDS
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-                const float *vp = v + (tb + (key < L ? key : L - 1)) * CV + nl;
+                const float *vp = Vs + ((r & 3) + 8 * (r >> 2) + 4 * hl) * VLD + nl;
 #pragma unroll
                 for (int j = 0; j < NVT; ++j) o[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * j], s[r], o[j], 0, 0, 0);
             }
@@ -348,8 +405,7 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
             float ax = 0.f, ay = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-                const float2 vv = *reinterpret_cast<const float2 *>(v + (tb + (key < L ? key : L - 1)) * 2);
+                const float2 vv = *reinterpret_cast<const float2 *>(Vs + ((r & 3) + 8 * (r >> 2) + 4 * hl) * 2);
                 ax += s[r] * vv.x;
                 ay += s[r] * vv.y;
             }
@@ -357,6 +413,11 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
             ay += __shfl_xor(ay, 32, 64);
             o2x = o2x * corr + ax;
             o2y = o2y * corr + ay;
+        }
+        __syncthreads();                 // every wave is done with this tile
+        if (more) {
+            stage();
+            __syncthreads();
         }
     }
     const float inv = 1.0f / l_run;
