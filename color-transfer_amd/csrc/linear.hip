@@ -472,14 +472,20 @@ static int check_ws(const void *ws, size_t ws_bytes, int n_images) {
     return CT_OK;
 }
 
+// Optional HIP events bracketing the two streaming kernels of the Reinhard path (bench.py's roofline measurement):
+// set with ct_profile_events(); NULL = off.  Recorded on the launch stream, so they time exactly one kernel.
+static hipEvent_t g_prof_evt[4] = {nullptr, nullptr, nullptr, nullptr};
+
 template <typename T, bool LAB>
 static int launch_moments(const T *base0, const T *base1, int n_first, int n_images, int64_t n_pixels,
                           const WsLayout &l, double *stats, hipStream_t s) {
     if (n_images == 0) return CT_OK;
     const int G = blocks_per_image(n_pixels >> 2, n_images);
+    if (LAB && g_prof_evt[0]) (void)hipEventRecord(g_prof_evt[0], s);
     hipLaunchKernelGGL((moments_kernel<T, LAB>), dim3(G, n_images), dim3(kBlock), 0, s, base0, base1, n_first,
                        n_pixels, l.partials, l.pivots);
     CT_CHECK_LAUNCH();
+    if (LAB && g_prof_evt[1]) (void)hipEventRecord(g_prof_evt[1], s);
     hipLaunchKernelGGL((moments_finalize_kernel<LAB>), dim3(n_images), dim3(kBlock), 0, s, l.partials, l.pivots, G,
                        n_pixels, stats);
     CT_CHECK_LAUNCH();
@@ -491,9 +497,11 @@ static int launch_reinhard_apply(const T *target, const double *st, const double
                                  int batch, hipStream_t s) {
     if (batch == 0 || n_pixels == 0) return CT_OK;
     const int G = blocks_per_image(n_pixels >> 2, batch);
+    if (g_prof_evt[2]) (void)hipEventRecord(g_prof_evt[2], s);
     hipLaunchKernelGGL((reinhard_apply_kernel<T, OUT_LAB>), dim3(G, batch), dim3(kBlock), 0, s, target, st, sr, out,
                        n_pixels);
     CT_CHECK_LAUNCH();
+    if (g_prof_evt[3]) (void)hipEventRecord(g_prof_evt[3], s);
     return CT_OK;
 }
 
@@ -620,6 +628,13 @@ static int mk_impl(const T *target, const T *reference, TO *out, int64_t n_pixel
 extern "C" {
 
 int ct_abi_version(void) { return CT_ABI_VERSION; }
+
+void ct_profile_events(void *moments_start, void *moments_stop, void *apply_start, void *apply_stop) {
+    ct::g_prof_evt[0] = (hipEvent_t)moments_start;
+    ct::g_prof_evt[1] = (hipEvent_t)moments_stop;
+    ct::g_prof_evt[2] = (hipEvent_t)apply_start;
+    ct::g_prof_evt[3] = (hipEvent_t)apply_stop;
+}
 
 const char *ct_error_string(int code) {
     switch (code) {

@@ -30,6 +30,7 @@ _c_sz = ctypes.c_size_t
 SIGNATURES = {
     "ct_abi_version": (_c_int, []),
     "ct_error_string": (ctypes.c_char_p, [_c_int]),
+    "ct_profile_events": (None, [_c_p, _c_p, _c_p, _c_p]),
     "ct_workspace_bytes": (_c_sz, [_c_int, _c_i64, _c_int]),
     "ct_lab_stats_f32": (_c_int, [_c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
     "ct_lab_stats_f64": (_c_int, [_c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
@@ -138,6 +139,15 @@ def _suffix(t):
     if t.dtype == torch.float64:
         return "f64"
     raise CtHipError("unsupported dtype %s (float32/float64 only)" % t.dtype)
+
+
+def profile_events(events):
+    """events: None (off) or four torch.cuda.Event(enable_timing=True) that have been recorded once (so that their
+    hipEvent_t exists); the library re-records them around moments_kernel / reinhard_apply_kernel."""
+    if events is None:
+        lib().ct_profile_events(None, None, None, None)
+    else:
+        lib().ct_profile_events(*[ctypes.c_void_p(e.cuda_event) for e in events])
 
 
 def lab_stats(img):

@@ -47,6 +47,10 @@ enum ct_workspace_kind {
 };
 
 int ct_abi_version(void);
+/* Measurement hook: four hipEvent_t (or NULL = off) that the library records on the launch stream immediately before /
+ * after moments_kernel<T,true> and reinhard_apply_kernel of the following ct_lab_stats / ct_reinhard* calls, so that a
+ * caller can time exactly those kernels with hipEventElapsedTime (bench.py `roofline`).  Not thread safe.              */
+void ct_profile_events(void *moments_start, void *moments_stop, void *apply_start, void *apply_stop);
 /* Human readable text for a return code of this library (never NULL). */
 const char *ct_error_string(int code);
 /* Bytes of device workspace an entry of `kind` needs for `n_images` images of `n_pixels`. */
