@@ -106,6 +106,7 @@ __device__ __forceinline__ void rgb_to_f(double r, double g, double b, double &f
     fz = lab_f_cbrt(z);
     const bool toe = !((x > 0.008856) & (y > 0.008856) & (z > 0.008856));   // also true for NaN
     if (__builtin_amdgcn_ballot_w64(toe)) {
+        asm volatile("; lab toe" : "+v"(fx));   // keeps this a real branch (the compiler would flatten it into selects)
         fx = (x > 0.008856) ? fx : fma(7.787, x, 16.0 / 116.0);
         fy = (y > 0.008856) ? fy : fma(7.787, y, 16.0 / 116.0);
         fz = (z > 0.008856) ? fz : fma(7.787, z, 16.0 / 116.0);
@@ -124,6 +125,7 @@ __device__ __forceinline__ void f_to_rgb(double fx, double fy, double fz, double
     double x = (fx * fx) * fx, y = (fy * fy) * fy, z = (fz * fz) * fz;
     const bool toe = !((fx > 0.2068966) & (fy > 0.2068966) & (fz > 0.2068966));
     if (__builtin_amdgcn_ballot_w64(toe)) {  // wave-uniform: the linear toe is rare
+        asm volatile("; lab toe" : "+v"(x));
         x = (fx > 0.2068966) ? x : fma(fx, 1.0 / 7.787, -(16.0 / 116.0) / 7.787);
         y = (fy > 0.2068966) ? y : fma(fy, 1.0 / 7.787, -(16.0 / 116.0) / 7.787);
         z = (fz > 0.2068966) ? z : fma(fz, 1.0 / 7.787, -(16.0 / 116.0) / 7.787);

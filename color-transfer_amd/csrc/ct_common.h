@@ -1,5 +1,6 @@
 // ct_common.h -- shared launch / reduction helpers for libct_hip.so (gfx950 only).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -12,10 +13,14 @@ constexpr int kWave = 64;
 constexpr int kMaxBlocksPerImage = 1024;
 // total workgroups a streaming launch aims for: 256 CUs x 8 (guide: cap ~2048, grid-stride the rest)
 constexpr int kTargetBlocks = 2048;
+inline int target_blocks() {
+    static int v = [] { const char *e = getenv("CT_HIP_TARGET_BLOCKS"); int x = e ? atoi(e) : 0; return x > 0 ? x : kTargetBlocks; }();
+    return v;
+}
 
 inline int blocks_per_image(int64_t n_chunks, int n_images) {
     int64_t want = (n_chunks + kBlock - 1) / kBlock;
-    int64_t cap = kTargetBlocks / (n_images > 0 ? n_images : 1);
+    int64_t cap = target_blocks() / (n_images > 0 ? n_images : 1);
     if (cap < 8) cap = 8;
     if (cap > kMaxBlocksPerImage) cap = kMaxBlocksPerImage;
     if (want > cap) want = cap;

@@ -72,8 +72,13 @@ __device__ __forceinline__ void accumulate(double (&s)[LAB ? 6 : 9], const doubl
 
 // grid = (G, n_images). Images [0, n_first) live at base0, the rest at base1 (so that the
 // targets and references of a batch of pairs are swept by ONE launch).
+// CT_WPE: optional occupancy attribute for tuning builds (tools/sweep_reinhard.sh); forcing 8 waves/SIMD spills and
+// is slower, the kernels are VALU-bound and insensitive to the grid (measured r01).
+#ifndef CT_WPE
+#define CT_WPE
+#endif
 template <typename T, bool LAB>
-__global__ __launch_bounds__(kBlock) void moments_kernel(const T *__restrict__ base0, const T *__restrict__ base1,
+__global__ __launch_bounds__(kBlock) CT_WPE void moments_kernel(const T *__restrict__ base0, const T *__restrict__ base1,
                                                          int n_first, int64_t n_pixels, double *__restrict__ partials,
                                                          double *__restrict__ pivots) {
     constexpr int NV = LAB ? 6 : 9;
@@ -214,7 +219,7 @@ __device__ __forceinline__ void reinhard_pixel(const ReinhardCoef &c, double r, 
 }
 
 template <typename T, bool OUT_LAB>
-__global__ __launch_bounds__(kBlock) void reinhard_apply_kernel(const T *__restrict__ target,
+__global__ __launch_bounds__(kBlock) CT_WPE void reinhard_apply_kernel(const T *__restrict__ target,
                                                                 const double *__restrict__ stats_t,
                                                                 const double *__restrict__ stats_r, T *__restrict__ out,
                                                                 int64_t n_pixels) {

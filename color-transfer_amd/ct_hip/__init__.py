@@ -15,7 +15,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libct_hip.so")
+LIB_PATH = os.environ.get("CT_HIP_LIB") or os.path.join(_HERE, "libct_hip.so")   # CT_HIP_LIB: tuning builds only
 
 CT_LAB_STATS_STRIDE = 8
 CT_RGB_STATS_STRIDE = 16
