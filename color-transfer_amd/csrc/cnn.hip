@@ -18,6 +18,7 @@
 // Arithmetic is float32 in, float32 accumulate (bitwise an fmaf chain in k order): the dense
 // peak this path is priced against is the FP32 matrix rate, 157.3 TFLOP/s.
 #include "ct_common.h"
+#include "ct_conv.h"
 
 namespace ct {
 
@@ -35,35 +36,34 @@ constexpr int kNumCUs = 256;    // MI355X
 //          dynamic LDS = halo tile + 2 weight slices (double buffer); the NEXT tile's halo is prefetched into
 //          registers (43 VGPRs) while the current one is multiplied, so HBM/L2 latency hides under the MFMAs
 // ---------------------------------------------------------------------------------------------
-struct ConvArgs {
-    const float *in;
-    const float *wp;
-    const float *bias;      // [MT*32], zero padded
-    const float *residual;  // nullable, same shape/strides as out
-    float *out;
-    int cin, cout, H, W;
-    long long in_bstride, out_bstride, res_bstride;   // elements between images of a batch
-    int act;     // 0 none, 1 LeakyReLU(0.01)
-    int clamp;   // 1 = clamp to [0,1]
-    unsigned long long *prof;   // diagnostic builds only (CT_CONV_PROFILE); NULL otherwise
-};
 
-template <int KS, int MT, bool VEC>
+__device__ __forceinline__ float conv_act(float v, int act) {
+    switch (act) {
+        case 1: return v > 0.f ? v : 0.01f * v;
+        case 2: return v > 0.f ? v : 0.f;
+        case 3: return 1.0f / (1.0f + expf(-v));
+        case 4: return tanhf(v);
+        default: return v;
+    }
+}
+
+template <int KH, int KW, int MT, bool VEC>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles_x, int tiles_y, int n_tiles) {
-    constexpr int PAD = KS / 2;
-    constexpr bool HALO = (KS == 3);
-    constexpr int ROWS = kConvTH + KS - 1;
+    constexpr int PADY = KH / 2, PADX = KW / 2;
+    constexpr bool HALO = (KW > 1);
+    constexpr int ROWS = kConvTH + KH - 1;
     constexpr int TWP = HALO ? kConvTW + 8 : kConvTW;   // LDS row = image columns [x0-4, x0+36): the 32 centre columns are 16-byte aligned
     constexpr int COL0 = HALO ? 4 : 0;                  // LDS column of image column x0
     constexpr int CS = ROWS * TWP;                      // floats per channel in the LDS tile
     constexpr int NV4 = kConvChunk * ROWS * (kConvTW / 4);   // centre float4 of one staged (tile, 32-channel chunk)
     constexpr int PF4 = NV4 / 256;                      // 10 (3x3) / 8 (1x1) per thread, exact
-    constexpr int NE = HALO ? kConvChunk * ROWS * 2 : 0;     // the two halo columns x0-1 and x0+32
-    constexpr int PFE = (NE + 255) / 256;               // 3 / 0
+    constexpr int HC = KW - 1;                          // halo columns: x0-PADX..x0-1 and x0+32..x0+31+PADX
+    constexpr int NE = kConvChunk * ROWS * HC;
+    constexpr int PFE = (NE + 255) / 256;               // 3 (3x3) / 4 (1x5) / 0
     static_assert(NV4 % 256 == 0, "tile geometry");
     constexpr int COUTP = MT * 32;
     constexpr int RPW = kConvTH / 4;           // output rows per wave
-    constexpr int TAPS = KS * KS;
+    constexpr int TAPS = KH * KW;
     extern __shared__ float smem[];
     float *tin = smem;                         // [kConvChunk][ROWS][TWP]
     float *stg = smem + kConvChunk * CS + (threadIdx.x >> 6) * (32 * 32);   // per-wave [32 ch][32 px] transpose buffer
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
     const unsigned int uplane = (unsigned int)plane;
     auto fetch_tile = [&](int stage) {
         const int k = stage / n_chunks, chunk = stage - k * n_chunks;
-        const int t = blockIdx.x + k * gridDim.x;
+        const int t = (blockIdx.x + k * gridDim.x) / a.groups;   // the group index varies fastest: neighbours share the input tile
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
         const int x0 = tx * kConvTW, y0 = ty * kConvTH, c0 = chunk * kConvChunk;
         const int cc = (a.cin - c0) < kConvChunk ? (a.cin - c0) : kConvChunk;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
             asm volatile("" : "+v"(f));
             const int c = f / (ROWS * 8), rem = f - c * (ROWS * 8);
             const int yy = rem >> 3, g = rem & 7;
-            const int gy = y0 + yy - PAD, gx = x0 + 4 * g;
+            const int gy = y0 + yy - PADY, gx = x0 + 4 * g;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (c < cc && gy >= 0 && gy < a.H) {
                 const float *p = in + (unsigned int)c * uplane + (unsigned int)(gy * a.W + gx);
@@ -116,9 +116,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
             for (int j = 0; j < PFE; ++j) {
                 int e = tid + j * 256;
                 asm volatile("" : "+v"(e));
-                const int c = e / (ROWS * 2), rem = e - c * (ROWS * 2);
-                const int yy = rem >> 1, side = rem & 1;
-                const int gy = y0 + yy - PAD, gx = side ? x0 + kConvTW : x0 - 1;
+                const int c = e / (ROWS * HC), rem = e - c * (ROWS * HC);
+                const int yy = rem / HC, side = rem - yy * HC;
+                const int gy = y0 + yy - PADY, gx = side < PADX ? x0 - PADX + side : x0 + kConvTW + side - PADX;
                 float v = 0.f;
                 if (e < NE && c < cc && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
                     v = in[(unsigned int)c * uplane + (unsigned int)(gy * a.W + gx)];
@@ -140,9 +140,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
             for (int j = 0; j < PFE; ++j) {
                 int e = tid + j * 256;
                 asm volatile("" : "+v"(e));
-                const int c = e / (ROWS * 2), rem = e - c * (ROWS * 2);
-                const int yy = rem >> 1, side = rem & 1;
-                if (e < NE) tin[c * CS + yy * TWP + (side ? COL0 + kConvTW : COL0 - 1)] = pfe[j];
+                const int c = e / (ROWS * HC), rem = e - c * (ROWS * HC);
+                const int yy = rem / HC, side = rem - yy * HC;
+                if (e < NE) tin[c * CS + yy * TWP + (side < PADX ? COL0 - PADX + side : COL0 + kConvTW + side - PADX)] = pfe[j];
             }
         }
     };
@@ -150,11 +150,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
     // (all waves of all workgroups read the same 147 KB: it lives in L2/L1; no LDS staging and therefore
     //  no barrier per tap -- the waves of a workgroup only meet twice per stage)
     constexpr int KSTEPS = kConvChunk / 2;
-    auto load_w = [&](int chunk, int tap, float (&w)[KSTEPS][MT]) {
+    auto load_w = [&](int grp, int chunk, int tap, float (&w)[KSTEPS][MT]) {
         const int c0 = chunk * kConvChunk;
         const int cc = (a.cin - c0) < kConvChunk ? (a.cin - c0) : kConvChunk;
         const int ccp = (cc + 1) >> 1;
-        const float *src = a.wp + ((size_t)tap * cin_pairs_total + (c0 >> 1)) * 2 * COUTP + hl * COUTP + nl;
+        const float *src = a.wp + (((size_t)grp * TAPS + tap) * cin_pairs_total + (c0 >> 1)) * 2 * COUTP + hl * COUTP + nl;
 #pragma unroll
         for (int p = 0; p < KSTEPS; ++p)
 #pragma unroll
@@ -194,9 +194,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
     // (tools/ubench/store_rates.hip).  With VEC both go through a per-wave 32x32 LDS transpose instead: global
     // traffic is 16 bytes per lane (8 channel rows x 128 B per instruction), LDS does the re-layout.
     auto init_acc = [&](int k) {
-        const int t = blockIdx.x + k * gridDim.x;
+        const int tg = blockIdx.x + k * gridDim.x, t = tg / a.groups, grp = tg - t * a.groups;
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
-        const float *__restrict__ res = res_in_acc ? a.residual + (size_t)n * a.res_bstride : nullptr;
+        const float *__restrict__ res = res_in_acc ? a.residual + (size_t)n * a.res_bstride + (size_t)grp * COUTP * plane : nullptr;
+        const int cout_g = a.cout - grp * COUTP;   // channels of this group that exist
         if (VEC) {
             // raw float4 rows land in the accumulator registers; finish_acc() re-lays them out at tile start
             const int x4 = tx * kConvTW + 4 * (lane & 7);
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
                     for (int j = 0; j < 4; ++j) {
                         const int co = m * 32 + (lane >> 3) + 8 * j;
                         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (inb && co < a.cout) v = *reinterpret_cast<const float4 *>(res + (unsigned int)co * uplane + pix);
+                        if (inb && co < cout_g) v = *reinterpret_cast<const float4 *>(res + (unsigned int)co * uplane + pix);
                         acc[q][m][4 * j + 0] = v.x; acc[q][m][4 * j + 1] = v.y;
                         acc[q][m][4 * j + 2] = v.z; acc[q][m][4 * j + 3] = v.w;
                     }
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
                     for (int r = 0; r < 16; ++r) {
                         const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
                         float v = 0.f;
-                        if (inb && co < a.cout) v = res[(unsigned int)co * uplane + pix];
+                        if (inb && co < cout_g) v = res[(unsigned int)co * uplane + pix];
                         acc[q][m][r] = v;
                     }
             }
@@ -252,12 +253,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
                 __builtin_amdgcn_wave_barrier();
             }
     };
-    load_w(0, 0, wa);
+    load_w((int)blockIdx.x % a.groups, 0, 0, wa);
     fetch_tile(0);
     init_acc(0);
     store_tile();
     for (int stage = 0; stage < n_stages; ++stage) {
         const int k = stage / n_chunks, chunk = stage - k * n_chunks;
+        const int grp = (int)((blockIdx.x + k * gridDim.x) % a.groups);
         if (chunk == 0) {
             finish_acc();
             // the accumulators were pre-loaded with the residual (or zero) by init_acc(); add the bias here, so
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
             for (int m = 0; m < MT; ++m) {
                 float bv[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) bv[r] = a.bias[m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl];   // padded
+                for (int r = 0; r < 16; ++r) bv[r] = a.bias[grp * COUTP + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl];   // padded
 #pragma unroll
                 for (int q = 0; q < RPW; ++q)
 #pragma unroll
@@ -278,9 +280,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
         CT_PHASE(1);
         const bool next_stage = (stage + 1 < n_stages);
         const int next_chunk = (chunk + 1 == n_chunks) ? 0 : chunk + 1;
+        const int next_grp = (next_chunk == 0) ? (int)((blockIdx.x + (k + 1) * gridDim.x) % a.groups) : grp;
         auto compute_tap = [&](int tap, const float (&w)[KSTEPS][MT]) {
-            const int ky = tap / KS, kx = tap - ky * KS;
-            const float *brow = tin + hl * CS + (wave * RPW + ky) * TWP + (COL0 - PAD) + kx + nl;
+            const int ky = tap / KW, kx = tap - ky * KW;
+            const float *brow = tin + hl * CS + (wave * RPW + ky) * TWP + (COL0 - PADX) + kx + nl;
             // B operands are read one k-step ahead of the MFMAs that consume them, and the scheduler is
             // pinned to "1 LDS read, then RPW*MT MFMAs" groups: a wave that has the matrix pipe to itself
             // (partner in its epilogue) then issues back to back instead of exposing the LDS latency per step
@@ -308,13 +311,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
         for (int tap = 0; tap < TAPS; ++tap) {
             const bool last_tap = (tap + 1 == TAPS);
             if ((tap & 1) == 0) {
-                if (!last_tap) load_w(chunk, tap + 1, wb);
-                else if (next_stage) load_w(next_chunk, 0, wb);
+                if (!last_tap) load_w(grp, chunk, tap + 1, wb);
+                else if (next_stage) load_w(next_grp, next_chunk, 0, wb);
                 if (tap == 0 && next_stage) fetch_tile(stage + 1);   // next halo tile: in flight under this stage's MFMAs
                 compute_tap(tap, wa);
             } else {
-                if (!last_tap) load_w(chunk, tap + 1, wa);
-                else if (next_stage) load_w(next_chunk, 0, wa);
+                if (!last_tap) load_w(grp, chunk, tap + 1, wa);
+                else if (next_stage) load_w(next_grp, next_chunk, 0, wa);
                 compute_tap(tap, wb);
             }
         }
@@ -327,12 +330,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
         CT_PHASE(2);                                       // tap loop (MFMAs + prefetch issue)
         if (chunk + 1 == n_chunks) {
             // ---- epilogue: lane owns pixels (y0 + wave*RPW + q, x0+nl), channels (r&3)+8(r>>2)+4hl of each 32-tile ----
-            const int t = blockIdx.x + k * gridDim.x;
+            const int t = (blockIdx.x + k * gridDim.x) / a.groups;
             const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
-            float *__restrict__ out = a.out + (size_t)n * a.out_bstride;
-            const float *__restrict__ res = a.residual ? a.residual + (size_t)n * a.res_bstride : nullptr;
-            const bool late_res = (res != nullptr) && !res_in_acc;   // LeakyReLU *and* a skip: not in this model
-            const bool full = (a.cout == COUTP);   // uniform: no per-channel predicate in the common case
+            float *__restrict__ out = a.out + (size_t)n * a.out_bstride + (size_t)grp * COUTP * plane;
+            const float *__restrict__ res = a.residual ? a.residual + (size_t)n * a.res_bstride + (size_t)grp * COUTP * plane : nullptr;
+            const bool late_res = (res != nullptr) && !res_in_acc;   // an activation *and* a skip: not in these models
+            const int cout_g = a.cout - grp * COUTP;
+            const bool full = (cout_g >= COUTP);   // uniform: no per-channel predicate in the common case
             const bool wide = VEC && !late_res && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
 #pragma unroll
             for (int q = 0; q < RPW; ++q) {
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             float v = acc[q][m][r];
-                            if (a.act == 1) v = v > 0.f ? v : 0.01f * v;
+                            if (a.act) v = conv_act(v, a.act);
                             if (a.clamp) v = fminf(fmaxf(v, 0.f), 1.f);
                             stg[((r & 3) + 8 * (r >> 2) + 4 * hl) * 32 + nl] = v;
                         }
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
                         for (int j = 0; j < 4; ++j) {
                             const int co = m * 32 + (lane >> 3) + 8 * j;
                             const float4 v = *reinterpret_cast<const float4 *>(stg + ((lane >> 3) + 8 * j) * 32 + 4 * (lane & 7));
-                            if (y < a.H && x4 < a.W && (full || co < a.cout))
+                            if (y < a.H && x4 < a.W && (full || co < cout_g))
                                 *reinterpret_cast<float4 *>(out + (unsigned int)co * uplane + (unsigned int)(y * a.W + x4)) = v;
                         }
                         __builtin_amdgcn_wave_barrier();
@@ -368,10 +372,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
                             for (int r = 0; r < 16; ++r) {
                                 const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
                                 float v = acc[q][m][r];
-                                if (a.act == 1) v = v > 0.f ? v : 0.01f * v;
-                                if (late_res && (full || co < a.cout)) v += res[(unsigned int)co * uplane + pix];
+                                if (a.act) v = conv_act(v, a.act);
+                                if (late_res && (full || co < cout_g)) v += res[(unsigned int)co * uplane + pix];
                                 if (a.clamp) v = fminf(fmaxf(v, 0.f), 1.f);
-                                if (full || co < a.cout) out[(unsigned int)co * uplane + pix] = v;
+                                if (full || co < cout_g) out[(unsigned int)co * uplane + pix] = v;
                             }
                         }
                     }
@@ -393,22 +397,32 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
 #endif
 }
 
-template <int KS, int MT>
-static int launch_conv(const ConvArgs &a, int N, hipStream_t s) {
-    constexpr int ROWS = kConvTH + KS - 1, TWP = (KS == 3) ? kConvTW + 8 : kConvTW;
+template <int KH, int KW, int MT>
+int launch_conv(const ConvArgs &a, int N, hipStream_t s) {
+    constexpr int ROWS = kConvTH + KH - 1, TWP = (KW > 1) ? kConvTW + 8 : kConvTW;
     const size_t lds = (size_t)(kConvChunk * ROWS * TWP + 4 * 32 * 32) * sizeof(float);
     // 16-byte loads need every (channel, row, 4-column group) address 16-byte aligned
     const bool vec = (a.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.in) & 15) == 0) && (a.in_bstride % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0) && (a.out_bstride % 4 == 0) &&
                      (!a.residual || (((reinterpret_cast<uintptr_t>(a.residual) & 15) == 0) && (a.res_bstride % 4 == 0)));
     const int tiles_x = (a.W + kConvTW - 1) / kConvTW, tiles_y = (a.H + kConvTH - 1) / kConvTH;
-    const long long n_tiles = (long long)tiles_x * tiles_y * N;
+    const long long n_tiles = (long long)tiles_x * tiles_y * N * a.groups;
     if (n_tiles > 0x7fffffffLL) return CT_E_BADARG;
     const int grid = n_tiles < 2 * kNumCUs ? (int)n_tiles : 2 * kNumCUs;   // persistent: two workgroups per CU
-    if (vec) hipLaunchKernelGGL((conv_mfma_kernel<KS, MT, true>), dim3(grid), dim3(256), lds, s, a, tiles_x, tiles_y, (int)n_tiles);
-    else hipLaunchKernelGGL((conv_mfma_kernel<KS, MT, false>), dim3(grid), dim3(256), lds, s, a, tiles_x, tiles_y, (int)n_tiles);
+    if (vec) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, MT, true>), dim3(grid), dim3(256), lds, s, a, tiles_x, tiles_y, (int)n_tiles);
+    else hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, MT, false>), dim3(grid), dim3(256), lds, s, a, tiles_x, tiles_y, (int)n_tiles);
     CT_CHECK_LAUNCH();
     return CT_OK;
+}
+
+// Stride-1 "same" convolutions with 64-channel output groups (GMFlow's backbone / refinement convs, gmflow.hip).
+// Returns 1 when the geometry has no fast kernel (the caller then uses its generic one).
+int conv_fast(const ConvArgs &a, int N, int kh, int kw, hipStream_t s) {
+    if (kh == 3 && kw == 3) return launch_conv<3, 3, 2>(a, N, s);
+    if (kh == 1 && kw == 1) return launch_conv<1, 1, 2>(a, N, s);
+    if (kh == 1 && kw == 5) return launch_conv<1, 5, 2>(a, N, s);
+    if (kh == 5 && kw == 1) return launch_conv<5, 1, 2>(a, N, s);
+    return 1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -679,11 +693,11 @@ int ct_conv2d_f32(const float *in, const float *wp, const float *bias, const flo
     a.in = in; a.wp = wp; a.bias = bias; a.residual = residual; a.out = out;
     a.cin = cin; a.cout = cout; a.H = h; a.W = w;
     a.in_bstride = in_bstride; a.out_bstride = out_bstride; a.res_bstride = res_bstride;
-    a.act = act; a.clamp = clamp; a.prof = nullptr;
+    a.act = act; a.clamp = clamp; a.groups = 1; a.prof = nullptr;
     hipStream_t s = (hipStream_t)stream;
     const int mt = cout > 32 ? 2 : 1;
-    if (ksize == 3) return mt == 2 ? ct::launch_conv<3, 2>(a, n, s) : ct::launch_conv<3, 1>(a, n, s);
-    return mt == 2 ? ct::launch_conv<1, 2>(a, n, s) : ct::launch_conv<1, 1>(a, n, s);
+    if (ksize == 3) return mt == 2 ? ct::launch_conv<3, 3, 2>(a, n, s) : ct::launch_conv<3, 3, 1>(a, n, s);
+    return mt == 2 ? ct::launch_conv<1, 1, 2>(a, n, s) : ct::launch_conv<1, 1, 1>(a, n, s);
 }
 
 #ifdef CT_CONV_PROFILE
@@ -694,8 +708,8 @@ int ct_conv2d_prof_f32(const float *in, const float *wp, const float *bias, cons
     a.in = in; a.wp = wp; a.bias = bias; a.residual = residual; a.out = out;
     a.cin = cin; a.cout = cout; a.H = h; a.W = w;
     a.in_bstride = (long long)cin * h * w; a.out_bstride = (long long)cout * h * w; a.res_bstride = a.out_bstride;
-    a.act = 0; a.clamp = 0; a.prof = prof;
-    return ct::launch_conv<3, 2>(a, n, (hipStream_t)stream);
+    a.act = 0; a.clamp = 0; a.groups = 1; a.prof = prof;
+    return ct::launch_conv<3, 3, 2>(a, n, (hipStream_t)stream);
 }
 #endif
 

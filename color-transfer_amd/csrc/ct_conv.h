@@ -1,0 +1,25 @@
+// ct_conv.h -- argument block of the LDS-tiled MFMA convolution (cnn.hip), shared with gmflow.hip
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ct {
+
+struct ConvArgs {
+    const float *in;
+    const float *wp;
+    const float *bias;      // [MT*32], zero padded
+    const float *residual;  // nullable, same shape/strides as out
+    float *out;
+    int cin, cout, H, W;
+    long long in_bstride, out_bstride, res_bstride;   // elements between images of a batch
+    int act;     // 0 none, 1 LeakyReLU(0.01), 2 ReLU, 3 sigmoid, 4 tanh
+    int clamp;   // 1 = clamp to [0,1]
+    int groups;  // output-channel groups of MT*32 (weights packed group-major); 1 for cout <= 64
+    unsigned long long *prof;   // diagnostic builds only (CT_CONV_PROFILE); NULL otherwise
+};
+
+// cnn.hip: stride-1, padding k/2, kernel 3x3 / 1x1 / 1x5 / 5x1, weights packed [group][tap][cin_pair][2][64];
+// returns CT_OK / an error, or 1 if (kh, kw) has no LDS-tiled kernel
+int conv_fast(const ConvArgs &a, int N, int kh, int kw, hipStream_t s);
+
+}  // namespace ct

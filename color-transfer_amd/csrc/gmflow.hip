@@ -15,6 +15,7 @@
 //   local_corr_softmax / local_corr_flow / local_attn_prop    matching.py:42-126, attention.py:220-256
 //   convex_upsample, bilinear_resize, flow_warp, fb_check, gru ops, elementwise   utils.py:137-155, geometry.py
 #include "ct_common.h"
+#include "ct_conv.h"
 
 namespace ct {
 
@@ -25,7 +26,7 @@ typedef float f32x16g __attribute__((ext_vector_type(16)));
 // K = (kh*kw) taps x input channels staged through LDS in chunks.
 // =================================================================================================
 struct GConvArgs {
-    const float *in, *wp, *bias;   // wp: [kh*kw][cin_pairs][2][coutp], coutp = 64*ceil(cout/64); bias padded to coutp (or null)
+    const float *in, *wp, *bias;   // wp: [coutp/64][kh*kw][cin_pairs][2][64], coutp = 64*ceil(cout/64); bias padded to coutp (or null)
     float *out;
     int cin, cout, coutp, H, W, Ho, Wo, KH, KW, stride, padH, padW;
     long long in_bstride, out_bstride;
@@ -76,10 +77,10 @@ __global__ __launch_bounds__(256, 2) void conv_generic_kernel(GConvArgs a, int t
         for (int tap = 0; tap < a.KH * a.KW; ++tap) {
             const int ky = tap / a.KW, kx = tap - ky * a.KW;
             const float *brow = tin + hl * CS + (wave * a.stride + ky) * TC + nl * a.stride + kx;
-            const float *wrow = a.wp + ((size_t)tap * cin_pairs + (c0 >> 1)) * 2 * a.coutp + hl * a.coutp + mt0 + nl;
+            const float *wrow = a.wp + (((size_t)blockIdx.y * a.KH * a.KW + tap) * cin_pairs + (c0 >> 1)) * 128 + hl * 64 + nl;
             for (int p = 0; p < ccp; ++p) {
                 const float b = brow[p * 2 * CS];
-                const float w0 = wrow[(size_t)p * 2 * a.coutp], w1 = wrow[(size_t)p * 2 * a.coutp + 32];
+                const float w0 = wrow[p * 128], w1 = wrow[p * 128 + 32];
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, b, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, b, acc[1], 0, 0, 0);
             }
@@ -762,6 +763,16 @@ int ct_gconv2d_f32(const float *in, const float *wp, const float *bias, float *o
     a.Ho = (h + 2 * pad_h - kh) / stride + 1; a.Wo = (w + 2 * pad_w - kw) / stride + 1;
     if (a.Ho < 1 || a.Wo < 1) return CT_E_BADARG;
     a.in_bstride = in_bstride; a.out_bstride = out_bstride; a.act = act;
+    if (stride == 1 && pad_h == kh / 2 && pad_w == kw / 2 && (kh & 1) && (kw & 1) && bias) {
+        // stride-1 "same" convolution: the LDS-tiled persistent kernel of cnn.hip (same weight layout)
+        ct::ConvArgs f;
+        f.in = in; f.wp = wp; f.bias = bias; f.residual = nullptr; f.out = out;
+        f.cin = cin; f.cout = cout; f.H = h; f.W = w;
+        f.in_bstride = in_bstride; f.out_bstride = out_bstride; f.res_bstride = 0;
+        f.act = act; f.clamp = 0; f.groups = a.coutp / 64; f.prof = nullptr;
+        const int rc = ct::conv_fast(f, n, kh, kw, (hipStream_t)stream);
+        if (rc != 1) return rc;
+    }
     const int TR = 3 * stride + kh, TC = 31 * stride + kw;
     int cchunk = (48 * 1024) / (TR * TC * 4);
     cchunk &= ~1;

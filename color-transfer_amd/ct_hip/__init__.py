@@ -435,15 +435,17 @@ def _opt(t):
 
 
 def pack_gconv_weight(weight, bias):
-    """Conv2d parameters -> ct_gconv2d_f32 layout: wp[kh*kw][ceil(cin/2)][2][64*ceil(cout/64)], bias padded."""
+    """Conv2d parameters -> ct_gconv2d_f32 layout: output channels in groups of 64 (zero padded),
+    wp[ceil(cout/64)][kh*kw][ceil(cin/2)][2][64]; bias zero padded to 64*ceil(cout/64) (zeros when the conv has none)."""
     cout, cin, kh, kw = weight.shape
     coutp, cinp = 64 * ((cout + 63) // 64), 2 * ((cin + 1) // 2)
     w = torch.zeros((coutp, cinp, kh, kw), dtype=torch.float32, device=weight.device)
     w[:cout, :cin] = weight.detach().float()
-    wp = w.permute(2, 3, 1, 0).reshape(kh * kw, cinp // 2, 2, coutp).contiguous()
-    b = None
+    # [g][co64][cin_pair][2][kh][kw] -> [g][kh][kw][cin_pair][2][co64]
+    wp = w.reshape(coutp // 64, 64, cinp // 2, 2, kh, kw).permute(0, 4, 5, 2, 3, 1).contiguous()
+    wp = wp.reshape(coutp // 64, kh * kw, cinp // 2, 2, 64)
+    b = torch.zeros(coutp, dtype=torch.float32, device=weight.device)
     if bias is not None:
-        b = torch.zeros(coutp, dtype=torch.float32, device=weight.device)
         b[:cout] = bias.detach().float()
     return wp, b
 

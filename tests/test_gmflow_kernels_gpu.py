@@ -32,7 +32,10 @@ def rnd(*shape):
     (2, 3, 64, 37, 70, 7, 7, 2, 3, 3), (1, 64, 96, 19, 35, 3, 3, 2, 1, 1), (1, 64, 96, 19, 35, 1, 1, 2, 0, 0),
     (1, 128, 128, 12, 33, 3, 3, 1, 1, 1), (1, 128, 128, 13, 34, 3, 3, 2, 1, 1), (2, 384, 128, 9, 40, 1, 5, 1, 0, 2),
     (1, 384, 128, 10, 33, 5, 1, 1, 2, 0), (1, 2, 128, 11, 37, 7, 7, 1, 3, 3), (1, 81, 256, 8, 32, 1, 1, 1, 0, 0),
-    (1, 256, 126, 8, 36, 3, 3, 1, 1, 1), (1, 256, 2, 8, 36, 3, 3, 1, 1, 1), (1, 256, 144, 8, 36, 1, 1, 1, 0, 0)])
+    (1, 256, 126, 8, 36, 3, 3, 1, 1, 1), (1, 256, 2, 8, 36, 3, 3, 1, 1, 1), (1, 256, 144, 8, 36, 1, 1, 1, 0, 0),
+    # multi-tile / multi-group geometries of the LDS-tiled stride-1 path (persistent schedule, 16-byte I/O)
+    (2, 96, 96, 40, 72, 3, 3, 1, 1, 1), (1, 130, 256, 24, 64, 3, 3, 1, 1, 1), (3, 384, 128, 20, 68, 1, 5, 1, 0, 2),
+    (3, 384, 128, 21, 68, 5, 1, 1, 2, 0), (2, 64, 192, 17, 100, 1, 1, 1, 0, 0)])
 def test_gconv(hip, cfg):
     n, cin, cout, h, w, kh, kw, s, ph, pw = cfg
     x, wt, b = rnd(n, cin, h, w), rnd(cout, cin, kh, kw) / (cin * kh * kw) ** 0.5, rnd(cout)
