@@ -171,56 +171,128 @@ __global__ void eltwise_kernel(const float *__restrict__ a, const float *__restr
 
 // =================================================================================================
 // nn.Linear on channels-last tokens: out[t][n] = act( sum_k x[t][k] W[n][k] + bias[n] )
-// One wave owns 32 tokens x 128 output features; A (tokens) and B (weight rows, PyTorch layout [N][K]) are read with
-// 16-byte loads straight into registers: the contraction index of the two lane halves is split as
-// k = hl*K/2 + p (any order is a valid dot product), so a lane needs K/2 CONSECUTIVE channels of its row.
-// K % 16 == 0 (128, 256, 1024 here).  grid = (ceil(T/32/4), ceil(N/128)); block = 4 waves = 128 tokens.
+// LDS-tiled "NT" GEMM: a workgroup owns 128 tokens x 128 features, each of its 4 waves a 64 x 64 quarter (2 x 2 MFMA
+// tiles).  K is walked in 32-channel chunks: both operands are K-contiguous in memory ([T][K] and PyTorch's [N][K]),
+// so a chunk of either is 128 rows x 128 bytes, fetched with fully coalesced 16-byte loads into registers while the
+// previous chunk is multiplied, then written to LDS rows of 36 floats (16-byte aligned, conflict-free 16-byte reads).
+// The contraction index of the two lane halves is split as k = 16*hl + p inside a chunk (any order is a valid dot
+// product), so the MFMA operands come out of LDS as float4.  The result goes through a per-wave 32x32 LDS transpose so
+// that it is stored 16 bytes per lane.  K % 16 == 0 (128, 256, 1024 here).  grid = (ceil(T/128), ceil(N/128)).
 // =================================================================================================
+constexpr int kLinLd = 36;   // LDS row stride in floats
+
 __global__ __launch_bounds__(256) void linear_tokens_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                             const float *__restrict__ bias, float *__restrict__ out,
                                                             long long T, int K, int N, int act /*0 none, 6 gelu*/) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nl = lane & 31, hl = lane >> 5;
-    const long long t0 = ((long long)blockIdx.x * 4 + wave) * 32;
+    __shared__ __attribute__((aligned(16))) float lds[2 * 128 * kLinLd];
+    float *Xs = lds, *Ws = lds + 128 * kLinLd;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, hl = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+    const long long t0 = (long long)blockIdx.x * 128;
     const int n0 = blockIdx.y * 128;
-    if (t0 >= T) return;
-    const int kh = K >> 1;
-    const long long trow = t0 + nl;
-    const float *xa = x + (trow < T ? trow : T - 1) * K + hl * kh;
-    f32x16g acc[4];
+
+    // staging: thread -> 4 (row, 16-byte column) slots of each operand tile
+    const int srow = tid >> 3, sq = tid & 7;
+    const float *xg[4], *wg[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    for (int k0 = 0; k0 < kh; k0 += 8) {
-        const float4 a0 = *reinterpret_cast<const float4 *>(xa + k0), a1 = *reinterpret_cast<const float4 *>(xa + k0 + 4);
-        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int nrow = n0 + j * 32 + nl;
-            const float *wb = w + (size_t)(nrow < N ? nrow : N - 1) * K + hl * kh + k0;
-            const float4 b0 = *reinterpret_cast<const float4 *>(wb), b1 = *reinterpret_cast<const float4 *>(wb + 4);
-            const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-            for (int p = 0; p < 8; ++p) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], bv[p], acc[j], 0, 0, 0);
-        }
+    for (int i = 0; i < 4; ++i) {
+        const long long tr = t0 + srow + 32 * i;
+        const int nr = n0 + srow + 32 * i;
+        xg[i] = x + (tr < T ? tr : T - 1) * K + 4 * sq;
+        wg[i] = w + (size_t)(nr < N ? nr : N - 1) * K + 4 * sq;
     }
-    // D[token i][feature j]: lane = feature, registers = tokens (r&3)+8(r>>2)+4hl
+    float4 px[4], pw[4];
+    auto fetch = [&](int kc) {
+        const bool inb = (kc + 4 * sq) < K;    // K % 4 == 0: a float4 is in range or not at all
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int nf = n0 + j * 32 + nl;
-        if (nf < N) {
-            const float bb = bias ? bias[nf] : 0.f;
+        for (int i = 0; i < 4; ++i) {
+            px[i] = inb ? *reinterpret_cast<const float4 *>(xg[i] + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pw[i] = inb ? *reinterpret_cast<const float4 *>(wg[i] + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4 *>(Xs + (srow + 32 * i) * kLinLd + 4 * sq) = px[i];
+            *reinterpret_cast<float4 *>(Ws + (srow + 32 * i) * kLinLd + 4 * sq) = pw[i];
+        }
+    };
+
+    f32x16g acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    fetch(0);
+    stage();
+    const float *xa = Xs + (wm * 64 + nl) * kLinLd + hl * 16;
+    const float *wb = Ws + (wn * 64 + nl) * kLinLd + hl * 16;
+    for (int kc = 0; kc < K; kc += 32) {
+        __syncthreads();                       // this chunk is visible
+        const bool more = (kc + 32) < K;
+        if (more) fetch(kc + 32);              // in flight under the MFMAs below
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(xa + 4 * q);
+            const float4 a1 = *reinterpret_cast<const float4 *>(xa + 32 * kLinLd + 4 * q);
+            const float4 b0 = *reinterpret_cast<const float4 *>(wb + 4 * q);
+            const float4 b1 = *reinterpret_cast<const float4 *>(wb + 32 * kLinLd + 4 * q);
+            const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
+            const float bv[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();                       // every wave is done with this chunk
+        if (more) stage();
+    }
+
+    // D[token][feature]: lane = feature column, registers = token rows (r&3)+8(r>>2)+4hl of the 32x32 tile.
+    // Per-wave transpose buffer (the operand tiles are dead after the last barrier): rows = tokens, 32 features each.
+    float *stg = lds + wave * (32 * 32);
+    const bool wide = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int f0 = n0 + wn * 64 + j * 32;
+            const long long tt0 = t0 + wm * 64 + i * 32;
+            const int nf = f0 + nl;
+            const float bb = (bias && nf < N) ? bias[nf] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const long long t = t0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-                if (t < T) {
-                    float v = acc[j][r] + bb;
-                    if (act == 6) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));   // exact GELU (nn.GELU default)
-                    out[t * N + nf] = v;
+                float v = acc[i][j][r] + bb;
+                if (act == 6) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));   // exact GELU (nn.GELU default)
+                acc[i][j][r] = v;
+            }
+            if (wide) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * hl) * 32 + nl] = acc[i][j][r];
+                __builtin_amdgcn_wave_barrier();
+                const int fc = f0 + 4 * (lane & 7);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = (lane >> 3) + 8 * g;
+                    const float4 v = *reinterpret_cast<const float4 *>(stg + row * 32 + 4 * (lane & 7));
+                    const long long t = tt0 + row;
+                    if (t < T && fc < N) *reinterpret_cast<float4 *>(out + t * N + fc) = v;   // N % 4 == 0: all four or none
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else if (nf < N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long t = tt0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+                    if (t < T) out[t * N + nf] = acc[i][j][r];
                 }
             }
         }
-    }
 }
 
 // LayerNorm over the last dim (C = 128, eps 1e-5, affine) of [T][128], optional residual: out = res + LN(x).
