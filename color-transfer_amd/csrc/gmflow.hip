@@ -630,44 +630,72 @@ __global__ __launch_bounds__(256) void local_corr_softmax_kernel(const float *__
 
 // matching.py:89-126: corr[b][t][y][x] = f0(y,x) . bilinear(f1, (x,y) + window[t] + flow) / sqrt(C), zeros padding,
 // align_corners=True (grid_sample of exactly representable pixel coordinates).  One wave per pixel, lanes over taps.
+// All (2R+1)^2 window taps of a pixel sample feature1 at integer offsets from ONE point (x + flow), so they share the
+// bilinear weights: corr(dx,dy) = w00 D(dx,dy) + w01 D(dx+1,dy) + w10 D(dx,dy+1) + w11 D(dx+1,dy+1) with the (2R+2)^2
+// integer-offset dots D(i,j) = <f0[pix], f1[y0-R+j][x0-R+i]> (zero outside the image = grid_sample's zero padding).
+// That is 100 dots per pixel instead of 4 x 81.  One wave per pixel at a time: lane <-> window position, walking its
+// 512-byte channel vector with 16-byte loads against the pixel's f0 vector broadcast from LDS.  A workgroup covers 32
+// consecutive pixels (4 waves x 8) and writes each of the 81 correlation planes as one 128-byte segment.
+constexpr int kLcfPix = 32;    // pixels per workgroup
+
 __global__ __launch_bounds__(256) void local_corr_flow_kernel(const float *__restrict__ f0, const float *__restrict__ f1,
                                                               const float *__restrict__ flow, float *__restrict__ corr, int H,
                                                               int W, int R, float scale) {
     constexpr int C = 128;
-    const int lane = threadIdx.x & 63;
-    const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ __attribute__((aligned(16))) float a_s[4][C];   // f0 vector of the pixel a wave is working on
+    __shared__ float d_s[4][128];                               // its integer-offset dots, (2R+2)^2 <= 100
+    __shared__ float o_s[81][kLcfPix + 1];                      // results [tap][pixel]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
-    if (pix >= (long long)H * W) return;
-    const int y = (int)(pix / W), x = (int)(pix % W);
-    const int D = 2 * R + 1, NT = D * D;
+    const int D = 2 * R + 1, NT = D * D, DP = D + 1, NP = DP * DP;
     const size_t hw = (size_t)H * W;
-    const float fx = flow[((size_t)b * 2 + 0) * hw + pix], fy = flow[((size_t)b * 2 + 1) * hw + pix];
-    const float *a = f0 + ((size_t)b * hw + pix) * C;
-    for (int t = lane; t < NT; t += 64) {
+    const long long pix0 = (long long)blockIdx.x * kLcfPix;
+    const float cx = (W - 1) * 0.5f, cy = (H - 1) * 0.5f;
+    for (int i = 0; i < kLcfPix / 4; ++i) {
+        const int pl = wave * (kLcfPix / 4) + i;
+        const long long pix = pix0 + pl;
+        if (pix >= (long long)hw) break;                        // wave-uniform
+        const int y = (int)(pix / W), x = (int)(pix % W);
+        const float fx = flow[((size_t)b * 2 + 0) * hw + pix], fy = flow[((size_t)b * 2 + 1) * hw + pix];
         // the reference normalises to [-1,1] and grid_sample maps back: ((g + 1) / 2) * (size - 1)
-        const float sx = (float)x + (float)(t % D - R) + fx, sy = (float)y + (float)(t / D - R) + fy;
-        const float cx = (W - 1) * 0.5f, cy = (H - 1) * 0.5f;
-        const float gx = (sx - cx) / cx, gy = (sy - cy) / cy;
+        const float gx = (((float)x + fx) - cx) / cx, gy = (((float)y + fy) - cy) / cy;
         const float px = ((gx + 1.0f) * 0.5f) * (float)(W - 1), py = ((gy + 1.0f) * 0.5f) * (float)(H - 1);
         const float x0f = floorf(px), y0f = floorf(py);
-        const int x0 = (int)x0f, y0 = (int)y0f;
         const float wx1 = px - x0f, wy1 = py - y0f, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
-        float acc = 0.f;
-#pragma unroll
-        for (int corner = 0; corner < 4; ++corner) {
-            const int xx = x0 + (corner & 1), yy = y0 + (corner >> 1);
-            const float wgt = ((corner & 1) ? wx1 : wx0) * ((corner >> 1) ? wy1 : wy0);
+        // clamp far-out-of-range bases (NaN/inf flows included) so that the int arithmetic below cannot overflow; every
+        // position is then outside the image and the row is all zeros, like grid_sample's
+        const int x0 = (x0f > -1e6f && x0f < 1e6f) ? (int)x0f : -1000000, y0 = (y0f > -1e6f && y0f < 1e6f) ? (int)y0f : -1000000;
+        *reinterpret_cast<float2 *>(&a_s[wave][2 * lane]) = *reinterpret_cast<const float2 *>(f0 + ((size_t)b * hw + pix) * C + 2 * lane);
+        __builtin_amdgcn_wave_barrier();
+        for (int p = lane; p < NP; p += 64) {
+            const int jj = p / DP, ii = p - jj * DP;
+            const int xx = x0 - R + ii, yy = y0 - R + jj;
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
             if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
                 const float *bp = f1 + ((size_t)b * hw + (size_t)yy * W + xx) * C;
-                float d = 0.f;
+#pragma unroll 8
                 for (int c = 0; c < C; c += 4) {
-                    const float4 u = *reinterpret_cast<const float4 *>(a + c), w4 = *reinterpret_cast<const float4 *>(bp + c);
-                    d += u.x * w4.x + u.y * w4.y + u.z * w4.z + u.w * w4.w;
+                    const float4 u = *reinterpret_cast<const float4 *>(&a_s[wave][c]);
+                    const float4 w4 = *reinterpret_cast<const float4 *>(bp + c);
+                    d0 = fmaf(u.x, w4.x, d0); d1 = fmaf(u.y, w4.y, d1); d2 = fmaf(u.z, w4.z, d2); d3 = fmaf(u.w, w4.w, d3);
                 }
-                acc += wgt * d;
             }
+            d_s[wave][p] = (d0 + d1) + (d2 + d3);
         }
-        corr[((size_t)b * NT + t) * hw + pix] = acc * scale;
+        __builtin_amdgcn_wave_barrier();
+        for (int t = lane; t < NT; t += 64) {
+            const int dy = t / D, dx = t - dy * D;
+            const float *dp = &d_s[wave][dy * DP + dx];
+            const float v = (wx0 * wy0) * dp[0] + (wx1 * wy0) * dp[1] + (wx0 * wy1) * dp[DP] + (wx1 * wy1) * dp[DP + 1];
+            o_s[t][pl] = v * scale;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NT * kLcfPix; e += 256) {
+        const int t = e / kLcfPix, pl = e - t * kLcfPix;
+        const long long pix = pix0 + pl;
+        if (pix < (long long)hw) corr[((size_t)b * NT + t) * hw + pix] = o_s[t][pl];
     }
 }
 
@@ -947,9 +975,9 @@ int ct_local_corr_softmax_f32(const float *f0, const float *f1, float *flow, int
 
 int ct_local_corr_flow_f32(const float *f0, const float *f1, const float *flow, float *corr, int batch, int h, int w, int radius,
                            void *stream) {
-    if (!f0 || !f1 || !flow || !corr || batch < 0 || h < 2 || w < 2 || radius < 0) return CT_E_BADARG;
+    if (!f0 || !f1 || !flow || !corr || batch < 0 || h < 2 || w < 2 || radius < 0 || radius > 4) return CT_E_BADARG;
     if (batch == 0) return CT_OK;
-    dim3 grid((unsigned)(((long long)h * w + 3) / 4), batch);
+    dim3 grid((unsigned)(((long long)h * w + ct::kLcfPix - 1) / ct::kLcfPix), batch);
     hipLaunchKernelGGL(ct::local_corr_flow_kernel, grid, dim3(256), 0, (hipStream_t)stream, f0, f1, flow, corr, h, w, radius,
                        1.0f / sqrtf(128.0f));
     CT_CHECK_LAUNCH();

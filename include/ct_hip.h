@@ -230,7 +230,7 @@ int ct_attention_colsum64_f32(const float *q, const float *k, const float *stats
 /* matching.py:42-86: flow[b][2][h][w] from the softmax over the (2r+1)^2 integer neighbourhood; f0,f1 tokens       */
 int ct_local_corr_softmax_f32(const float *f0, const float *f1, float *flow, int batch, int h, int w,
                               int radius, void *stream);
-/* matching.py:89-126: corr[b][(2r+1)^2][h][w] = f0 . bilinear(f1, pos + window + flow) / sqrt(128)               */
+/* matching.py:89-126: corr[b][(2r+1)^2][h][w] = f0 . bilinear(f1, pos + window + flow) / sqrt(128); radius <= 4   */
 int ct_local_corr_flow_f32(const float *f0, const float *f1, const float *flow, float *corr, int batch,
                            int h, int w, int radius, void *stream);
 /* attention.py:220-256: (2r+1)^2 local window attention of flow; q = q_proj(f), k = k_proj(f) as tokens          */
