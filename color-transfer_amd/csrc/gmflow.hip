@@ -333,8 +333,8 @@ __global__ __launch_bounds__(256) void layernorm_tokens_kernel(const float *__re
 template <int C, int CV>
 __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                                const float *__restrict__ v, const int *__restrict__ region,
-                                                               float *__restrict__ out, float *__restrict__ stats, int L,
-                                                               float scale) {
+                                                               const int *__restrict__ rowmap, float *__restrict__ out,
+                                                               float *__restrict__ stats, int L, float scale) {
     constexpr int CH = C / 2;                       // channels per lane half
     constexpr int NVT = CV >= 32 ? CV / 32 : 1;     // 32-channel value tiles on the MFMA path
     constexpr int KLD = C + 4;                      // padded LDS rows: the 16-lane column reads (b128) are conflict free
@@ -354,10 +354,13 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
     const int qi = q0 + nl;
     const bool qlive = qi < L;
     const int qclamp = qlive ? qi : L - 1;
+    // rowmap (optional): token (b, i) of this launch lives in row rowmap[b*L + i] of q / k / v / out -- the shifted-window
+    // partition of attention.py:60-92 as an index table instead of roll + permute copies
+    auto row = [&](int i) -> size_t { return rowmap ? (size_t)rowmap[tb + i] : tb + i; };
     // B operand of S^T = K Q^T : lane (query nl, half hl) holds q[query][hl*C/2 + p], p < C/2
     float qb[CH];
     {
-        const float *qp = q + (tb + qclamp) * C + hl * CH;
+        const float *qp = q + row(qclamp) * C + hl * CH;
 #pragma unroll
         for (int i = 0; i < CH / 4; ++i) {
             const float4 t = *reinterpret_cast<const float4 *>(qp + 4 * i);
@@ -368,23 +371,43 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
 
     float4 kpre[KV4], vpre[VV4];
     int rpre = 0;
+    // rows of the keys this thread stages, looked up ONE TILE AHEAD of the data loads that use them (a dependent
+    // index -> data load pair inside fetch() would double the latency the MFMAs of one tile have to hide)
+    size_t krow[KV4], vrow[CV >= 32 ? VV4 : 1];
+    auto fetch_rows = [&](int j0) {
+#pragma unroll
+        for (int i = 0; i < KV4; ++i) {
+            const int key = (tid + i * 256) / (C / 4);
+            krow[i] = row(j0 + key < L ? j0 + key : L - 1);
+        }
+        if (CV >= 32) {
+#pragma unroll
+            for (int i = 0; i < VV4; ++i) {
+                const int key = (tid + i * 256) / (CV / 4);
+                vrow[i] = row(j0 + key < L ? j0 + key : L - 1);
+            }
+        }
+    };
     auto fetch = [&](int j0) {
 #pragma unroll
         for (int i = 0; i < KV4; ++i) {
             const int f = tid + i * 256, key = f / (C / 4), c4 = f - key * (C / 4);
-            kpre[i] = (j0 + key < L) ? *reinterpret_cast<const float4 *>(k + (tb + j0 + key) * C + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            kpre[i] = (j0 + key < L) ? *reinterpret_cast<const float4 *>(k + krow[i] * C + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (CV >= 32) {
 #pragma unroll
             for (int i = 0; i < VV4; ++i) {
                 const int f = tid + i * 256, key = f / (CV / 4), c4 = f - key * (CV / 4);
-                vpre[i] = (j0 + key < L) ? *reinterpret_cast<const float4 *>(v + (tb + j0 + key) * CV + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                vpre[i] = (j0 + key < L) ? *reinterpret_cast<const float4 *>(v + vrow[i] * CV + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else if (CV == 2) {
             if (tid < 16) {   // 32 keys x 2 channels = 16 float4
                 const int key = 2 * tid;
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (j0 + key + 1 < L) t = *reinterpret_cast<const float4 *>(v + (tb + j0 + key) * 2);
+                if (rowmap) {
+                    if (j0 + key < L) { const float2 u = *reinterpret_cast<const float2 *>(v + row(j0 + key) * 2); t.x = u.x; t.y = u.y; }
+                    if (j0 + key + 1 < L) { const float2 u = *reinterpret_cast<const float2 *>(v + row(j0 + key + 1) * 2); t.z = u.x; t.w = u.y; }
+                } else if (j0 + key + 1 < L) t = *reinterpret_cast<const float4 *>(v + (tb + j0 + key) * 2);
                 else if (j0 + key < L) { const float2 u = *reinterpret_cast<const float2 *>(v + (tb + j0 + key) * 2); t.x = u.x; t.y = u.y; }
                 vpre[0] = t;
             }
@@ -418,12 +441,17 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
     }
+    fetch_rows(0);
     fetch(0);
+    fetch_rows(32);
     stage();
     __syncthreads();
     for (int j0 = 0; j0 < L; j0 += 32) {
         const bool more = j0 + 32 < L;
-        if (more) fetch(j0 + 32);
+        if (more) {
+            fetch(j0 + 32);
+            fetch_rows(j0 + 64);
+        }
         // ---- S^T tile: A = K rows (key nl) from LDS, B = Q ----
         f32x16g s;
 #pragma unroll
@@ -501,13 +529,16 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
     if (CV >= 32) {
         // O^T[c][query]: lane = query nl, registers = channels (r&3)+8(r>>2)+4hl of tile j
         if (qlive) {
+            float *op = out + row(qi) * CV;
 #pragma unroll
             for (int j = 0; j < NVT; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) out[(tb + qi) * CV + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl] = o[j][r] * inv;
+                for (int r = 0; r < 16; r += 4)   // registers r..r+3 are four consecutive channels
+                    *reinterpret_cast<float4 *>(op + j * 32 + 8 * (r >> 2) + 4 * hl) =
+                        make_float4(o[j][r] * inv, o[j][r + 1] * inv, o[j][r + 2] * inv, o[j][r + 3] * inv);
         }
     } else if (CV == 2) {
-        if (qlive && hl == 0) *reinterpret_cast<float2 *>(out + (tb + qi) * 2) = make_float2(o2x * inv, o2y * inv);
+        if (qlive && hl == 0) *reinterpret_cast<float2 *>(out + row(qi) * 2) = make_float2(o2x * inv, o2y * inv);
     }
 }
 
@@ -926,15 +957,15 @@ int ct_layernorm128_f32(const float *x, const float *gamma, const float *beta, c
     return CT_OK;
 }
 
-int ct_attention_tokens_f32(const float *q, const float *k, const float *v, const int *region, float *out, int batch, int len, int cv,
-                            float scale, void *stream) {
+int ct_attention_tokens_f32(const float *q, const float *k, const float *v, const int *region, const int *rowmap, float *out,
+                            int batch, int len, int cv, float scale, void *stream) {
     if (!q || !k || !v || !out || batch < 0 || len < 1 || (cv != 2 && cv != 128)) return CT_E_BADARG;
-    if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k)) & 15) return CT_E_ALIGN;
+    if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(out)) & 15) return CT_E_ALIGN;
     if (batch == 0) return CT_OK;
     dim3 grid((len + 127) / 128, batch);
     float *nostats = nullptr;
-    if (cv == 128) hipLaunchKernelGGL((ct::attention_tokens_kernel<128, 128>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, region, out, nostats, len, scale);
-    else hipLaunchKernelGGL((ct::attention_tokens_kernel<128, 2>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, region, out, nostats, len, scale);
+    if (cv == 128) hipLaunchKernelGGL((ct::attention_tokens_kernel<128, 128>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, region, rowmap, out, nostats, len, scale);
+    else hipLaunchKernelGGL((ct::attention_tokens_kernel<128, 2>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, region, rowmap, out, nostats, len, scale);
     CT_CHECK_LAUNCH();
     return CT_OK;
 }
@@ -946,8 +977,9 @@ int ct_attention_rows64_f32(const float *q, const float *k, const float *v, floa
     if (batch == 0) return CT_OK;
     dim3 grid((len + 127) / 128, batch);
     const int *noreg = nullptr;
-    if (v) hipLaunchKernelGGL((ct::attention_tokens_kernel<64, 96>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, noreg, out, stats, len, scale);
-    else hipLaunchKernelGGL((ct::attention_tokens_kernel<64, 0>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, noreg, out, stats, len, scale);
+    if (v && (reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(out)) & 15) return CT_E_ALIGN;
+    if (v) hipLaunchKernelGGL((ct::attention_tokens_kernel<64, 96>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, noreg, noreg, out, stats, len, scale);
+    else hipLaunchKernelGGL((ct::attention_tokens_kernel<64, 0>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, noreg, noreg, out, stats, len, scale);
     CT_CHECK_LAUNCH();
     return CT_OK;
 }

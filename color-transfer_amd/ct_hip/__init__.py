@@ -407,7 +407,7 @@ SIGNATURES.update({
     "ct_eltwise_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_f, _c_p]),
     "ct_linear_tokens_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p]),
     "ct_layernorm128_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_p]),
-    "ct_attention_tokens_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_p]),
+    "ct_attention_tokens_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_p]),
     "ct_attention_rows64_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_f, _c_p]),
     "ct_attention_colsum64_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_f, _c_p]),
     "ct_local_corr_softmax_f32": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
@@ -496,15 +496,26 @@ def layernorm128(x, gamma, beta, residual=None):
     return out
 
 
-def attention_tokens(q, k, v, region=None, scale=None):
-    """q,k [B,L,128], v [B,L,128] or [B,L,2]; region int32 [B,L] or None -> [B,L,cv]"""
+def attention_tokens(q, k, v, region=None, scale=None, rowmap=None):
+    """q,k [B,L,128], v [B,L,128] or [B,L,2]; region int32 [B,L] or None -> [B,L,cv].
+    With rowmap (int32 [B', L']): B' x L' attention problems whose token (b, i) is row rowmap[b, i] of the flattened
+    q / k / v / out -- window partitions without copies; the result has v's shape."""
     _f32c(q, k, v)
-    b, l, c = q.shape
-    cv = v.shape[-1]
-    if region is not None and (region.dtype != torch.int32 or not region.is_contiguous()):
-        raise CtHipError("region must be contiguous int32")
-    out = torch.empty((b, l, cv), dtype=torch.float32, device=q.device)
-    check(lib().ct_attention_tokens_f32(_ptr(q), _ptr(k), _ptr(v), _opt(region), _ptr(out), b, l, cv,
+    c, cv = q.shape[-1], v.shape[-1]
+    for t in (region, rowmap):
+        if t is not None and (t.dtype != torch.int32 or not t.is_contiguous()):
+            raise CtHipError("region / rowmap must be contiguous int32")
+    if rowmap is not None:
+        b, l = rowmap.shape
+        if region is not None and tuple(region.shape) != (b, l):
+            raise CtHipError("region and rowmap must have the same shape")
+        if b * l != q.numel() // c or b * l != v.numel() // cv or k.shape != q.shape:
+            raise CtHipError("rowmap must be a permutation of the token rows")
+        out = torch.empty_like(v)
+    else:
+        b, l, _ = q.shape
+        out = torch.empty((b, l, cv), dtype=torch.float32, device=q.device)
+    check(lib().ct_attention_tokens_f32(_ptr(q), _ptr(k), _ptr(v), _opt(region), _opt(rowmap), _ptr(out), b, l, cv,
                                         float(scale if scale is not None else c ** -0.5), _stream()))
     return out
 

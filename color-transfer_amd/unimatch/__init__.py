@@ -195,6 +195,18 @@ def _region_ids(h, w, splits, device):                 # unimatch/utils.py:87-10
     return _tables[key]
 
 
+def _window_rowmap(b, h, w, splits, shift, device):    # token rows of every (image, window), window-major
+    key = ("rowmap", b, h, w, splits, bool(shift), str(device))
+    if key not in _tables:
+        wh, ww = h // splits, w // splits
+        idx = torch.arange(b * h * w, dtype=torch.int32).view(b, h, w)
+        if shift:
+            idx = torch.roll(idx, shifts=(-(wh // 2), -(ww // 2)), dims=(1, 2))
+        idx = idx.view(b, splits, wh, splits, ww).permute(0, 1, 3, 2, 4).reshape(b * splits * splits, wh * ww)
+        _tables[key] = idx.contiguous().to(device)
+    return _tables[key]
+
+
 def _coords_tokens(b, h, w, device):                   # unimatch/geometry.py:8-25 as tokens [B, H*W, 2] (x, y)
     key = ("grid", b, h, w, str(device))
     if key not in _tables:
@@ -241,22 +253,12 @@ class GMFlow(nn.Module):
     # ---- unimatch/attention.py:48-107 on tokens ----
     @staticmethod
     def _window_attention(q, k, v, splits, shift, h, w):
-        b, _, c = q.shape
-        wh, ww = h // splits, w // splits
-
-        def to_windows(t):
-            t = t.view(b, h, w, c)
-            if shift:
-                t = torch.roll(t, shifts=(-(wh // 2), -(ww // 2)), dims=(1, 2))
-            return t.view(b, splits, wh, splits, ww, c).permute(0, 1, 3, 2, 4, 5).reshape(b * splits * splits, wh * ww, c).contiguous()
-        region = None
-        if shift:
-            region = _region_ids(h, w, splits, q.device).repeat(b, 1).contiguous()
-        out = ct_hip.attention_tokens(to_windows(q), to_windows(k), to_windows(v), region)
-        out = out.view(b, splits, splits, wh, ww, c).permute(0, 1, 3, 2, 4, 5).reshape(b, h, w, c)
-        if shift:
-            out = torch.roll(out, shifts=(wh // 2, ww // 2), dims=(1, 2))
-        return out.reshape(b, h * w, c).contiguous()
+        """split_feature / roll / merge_splits (attention.py:60-67,78-92,100-107) are one cached index table: the
+        kernel gathers the tokens of a window and scatters its result through it, nothing is copied"""
+        b = q.shape[0]
+        rowmap = _window_rowmap(b, h, w, splits, shift, q.device)
+        region = _region_ids(h, w, splits, q.device).repeat(b, 1).contiguous() if shift else None
+        return ct_hip.attention_tokens(q, k, v, region, rowmap=rowmap)
 
     def _tlayer(self, m, source, target, h, w, shift, splits):          # transformer.py:45-147
         q, k, v = _lin(m.q_proj, source), _lin(m.k_proj, target), _lin(m.v_proj, target)

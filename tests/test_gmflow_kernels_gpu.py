@@ -99,6 +99,34 @@ def test_attention_tokens(hip, b, l, cv, masked):
     close(out, ref, "attention", atol=5e-5, rtol=1e-4)
 
 
+@pytest.mark.parametrize("cv,shift", [(128, False), (128, True), (2, True)])
+def test_attention_rowmap_is_window_partition(hip, cv, shift):
+    """rowmap == split_feature + roll + merge_splits of the reference (attention.py:60-107), without the copies"""
+    b, h, w, splits, c = 2, 12, 20, 2, 128
+    wh, ww = h // splits, w // splits
+    q, k, v = rnd(b, h * w, c), rnd(b, h * w, c), rnd(b, h * w, cv)
+    idx = torch.arange(b * h * w, dtype=torch.int32).view(b, h, w)
+    if shift:
+        idx = torch.roll(idx, shifts=(-(wh // 2), -(ww // 2)), dims=(1, 2))
+    rowmap = idx.view(b, splits, wh, splits, ww).permute(0, 1, 3, 2, 4).reshape(b * splits * splits, wh * ww).contiguous()
+    region = torch.randint(0, 3, rowmap.shape, generator=G, dtype=torch.int32) if shift else None
+
+    def win(t):                                    # the reference's formulation on float64
+        t = t.double().view(b, h, w, -1)
+        if shift:
+            t = torch.roll(t, shifts=(-(wh // 2), -(ww // 2)), dims=(1, 2))
+        return t.view(b, splits, wh, splits, ww, -1).permute(0, 1, 3, 2, 4, 5).reshape(b * splits * splits, wh * ww, -1)
+    scores = torch.matmul(win(q), win(k).transpose(1, 2)) / c ** 0.5
+    if shift:
+        scores = scores + torch.where(region[:, :, None] != region[:, None, :], -100.0, 0.0)
+    ref = torch.matmul(torch.softmax(scores, dim=-1), win(v))
+    ref = ref.view(b, splits, splits, wh, ww, cv).permute(0, 1, 3, 2, 4, 5).reshape(b, h, w, cv)
+    if shift:
+        ref = torch.roll(ref, shifts=(wh // 2, ww // 2), dims=(1, 2))
+    out = hip.attention_tokens(q.cuda(), k.cuda(), v.cuda(), region.cuda() if shift else None, rowmap=rowmap.cuda())
+    close(out, ref.reshape(b, h * w, cv), "window attention through rowmap", atol=5e-5, rtol=1e-4)
+
+
 def test_local_corr_kernels(hip):
     b, h, w = 2, 13, 21
     f0, f1 = rnd(b, 128, h, w), rnd(b, 128, h, w)
