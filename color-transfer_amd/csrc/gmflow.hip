@@ -318,6 +318,29 @@ __global__ __launch_bounds__(256) void layernorm_tokens_kernel(const float *__re
     *reinterpret_cast<float2 *>(out + t * 128 + 2 * lane) = make_float2(o0, o1);
 }
 
+// Merge of the key splits of attention_tokens_kernel: out = sum_z o_z e^(m_z - M) / sum_z l_z e^(m_z - M).
+// grid = ceil(batch*len*CV / 256); one thread per output element.
+__global__ __launch_bounds__(256) void attention_combine_kernel(const float *__restrict__ part, const int *__restrict__ rowmap,
+                                                                float *__restrict__ out, long long tokens, int CV, int nsplit) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= tokens * CV) return;
+    const long long t = e / CV;
+    const int ch = (int)(e - t * CV);
+    const size_t zs = (size_t)tokens * (CV + 2);
+    const float *p = part + (size_t)t * (CV + 2);
+    float M = -INFINITY;
+    for (int z = 0; z < nsplit; ++z) M = fmaxf(M, p[z * zs + CV]);
+    float num = 0.f, den = 0.f;
+    for (int z = 0; z < nsplit; ++z) {
+        const float m = p[z * zs + CV];
+        const float wgt = (m == -INFINITY) ? 0.f : expf(m - M);
+        num += wgt * p[z * zs + ch];
+        den += wgt * p[z * zs + CV + 1];
+    }
+    const size_t row = rowmap ? (size_t)rowmap[t] : (size_t)t;
+    out[row * CV + ch] = num / den;
+}
+
 // =================================================================================================
 // Streaming single-head attention on channels-last tokens (C = 128):
 //   out[b][i][:] = sum_j softmax_j( q[b][i].k[b][j] / sqrt(C) + mask(i,j) ) v[b][j][:]
@@ -334,7 +357,8 @@ template <int C, int CV>
 __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                                const float *__restrict__ v, const int *__restrict__ region,
                                                                const int *__restrict__ rowmap, float *__restrict__ out,
-                                                               float *__restrict__ stats, int L, float scale) {
+                                                               float *__restrict__ stats, int L, float scale,
+                                                               float *__restrict__ part) {
     constexpr int CH = C / 2;                       // channels per lane half
     constexpr int NVT = CV >= 32 ? CV / 32 : 1;     // 32-channel value tiles on the MFMA path
     constexpr int KLD = C + 4;                      // padded LDS rows: the 16-lane column reads (b128) are conflict free
@@ -380,7 +404,7 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
             const int key = (tid + i * 256) / (C / 4);
             krow[i] = row(j0 + key < L ? j0 + key : L - 1);
         }
-        if (CV >= 32) {
+        if constexpr (CV >= 32) {
 #pragma unroll
             for (int i = 0; i < VV4; ++i) {
                 const int key = (tid + i * 256) / (CV / 4);
@@ -394,13 +418,13 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
             const int f = tid + i * 256, key = f / (C / 4), c4 = f - key * (C / 4);
             kpre[i] = (j0 + key < L) ? *reinterpret_cast<const float4 *>(k + krow[i] * C + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (CV >= 32) {
+        if constexpr (CV >= 32) {
 #pragma unroll
             for (int i = 0; i < VV4; ++i) {
                 const int f = tid + i * 256, key = f / (CV / 4), c4 = f - key * (CV / 4);
                 vpre[i] = (j0 + key < L) ? *reinterpret_cast<const float4 *>(v + vrow[i] * CV + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-        } else if (CV == 2) {
+        } else if constexpr (CV == 2) {
             if (tid < 16) {   // 32 keys x 2 channels = 16 float4
                 const int key = 2 * tid;
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -420,13 +444,13 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
             const int f = tid + i * 256, key = f / (C / 4), c4 = f - key * (C / 4);
             *reinterpret_cast<float4 *>(Ks + key * KLD + 4 * c4) = kpre[i];
         }
-        if (CV >= 32) {
+        if constexpr (CV >= 32) {
 #pragma unroll
             for (int i = 0; i < VV4; ++i) {
                 const int f = tid + i * 256, key = f / (CV / 4), c4 = f - key * (CV / 4);
                 *reinterpret_cast<float4 *>(Vs + key * VLD + 4 * c4) = vpre[i];
             }
-        } else if (CV == 2) {
+        } else if constexpr (CV == 2) {
             if (tid < 16) *reinterpret_cast<float4 *>(Vs + 4 * tid) = vpre[0];   // Vs[key*2 + ch]
         }
         if (region && tid < 32) Rs[tid] = rpre;
@@ -435,19 +459,25 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
     float m_run = -INFINITY, l_run = 0.f;
     f32x16g o[NVT];
     float o2x = 0.f, o2y = 0.f;
-    if (CV >= 32) {
+    if constexpr (CV >= 32) {
 #pragma unroll
         for (int j = 0; j < NVT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
     }
-    fetch_rows(0);
-    fetch(0);
-    fetch_rows(32);
+    // key split (gridDim.z > 1): this workgroup attends its queries to keys [jb, je) only and leaves the unnormalised
+    // partial (o, max, sum) in `part`; attention_combine_kernel merges the splits.  Fills the chip when batch*len/128
+    // workgroups would not (global matching: 56 of them on 256 CUs).
+    const int nsplit = gridDim.z, split = blockIdx.z;
+    const int kchunk = ((L + nsplit - 1) / nsplit + 31) & ~31;
+    const int jb = split * kchunk, je = (jb + kchunk < L) ? jb + kchunk : L;
+    fetch_rows(jb);
+    fetch(jb);
+    fetch_rows(jb + 32);
     stage();
     __syncthreads();
-    for (int j0 = 0; j0 < L; j0 += 32) {
-        const bool more = j0 + 32 < L;
+    for (int j0 = jb; j0 < je; j0 += 32) {
+        const bool more = j0 + 32 < je;
         if (more) {
             fetch(j0 + 32);
             fetch_rows(j0 + 64);
@@ -489,7 +519,7 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
         psum += __shfl_xor(psum, 32, 64);
         l_run = l_run * corr + psum;
         m_run = m_new;
-        if (CV >= 32) {
+        if constexpr (CV >= 32) {
 #pragma unroll
             for (int j = 0; j < NVT; ++j)
 #pragma unroll
@@ -502,7 +532,7 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
 #pragma unroll
                 for (int j = 0; j < NVT; ++j) o[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * j], s[r], o[j], 0, 0, 0);
             }
-        } else if (CV == 2) {
+        } else if constexpr (CV == 2) {
             float ax = 0.f, ay = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -521,12 +551,28 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
             __syncthreads();
         }
     }
+    if (nsplit > 1) {
+        // part: [split][batch][len][CV + 2]
+        float *pp = part + (((size_t)split * gridDim.y + b) * L + qclamp) * (CV + 2);
+        if (qlive) {
+            if constexpr (CV >= 32) {
+#pragma unroll
+                for (int j = 0; j < NVT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pp[j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl] = o[j][r];
+            } else if (CV == 2 && hl == 0) {
+                pp[0] = o2x; pp[1] = o2y;
+            }
+            if (hl == 0) { pp[CV] = m_run; pp[CV + 1] = l_run; }
+        }
+        return;
+    }
     const float inv = 1.0f / l_run;
     if (stats && qlive && hl == 0) {     // row statistics of the softmax (max, sum): used by the column-sum pass
         stats[(tb + qi) * 2] = m_run;
         stats[(tb + qi) * 2 + 1] = l_run;
     }
-    if (CV >= 32) {
+    if constexpr (CV >= 32) {
         // O^T[c][query]: lane = query nl, registers = channels (r&3)+8(r>>2)+4hl of tile j
         if (qlive) {
             float *op = out + row(qi) * CV;
@@ -537,7 +583,7 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
                     *reinterpret_cast<float4 *>(op + j * 32 + 8 * (r >> 2) + 4 * hl) =
                         make_float4(o[j][r] * inv, o[j][r + 1] * inv, o[j][r + 2] * inv, o[j][r + 3] * inv);
         }
-    } else if (CV == 2) {
+    } else if constexpr (CV == 2) {
         if (qlive && hl == 0) *reinterpret_cast<float2 *>(out + row(qi) * 2) = make_float2(o2x * inv, o2y * inv);
     }
 }
@@ -957,16 +1003,28 @@ int ct_layernorm128_f32(const float *x, const float *gamma, const float *beta, c
     return CT_OK;
 }
 
+size_t ct_attention_workspace_bytes(int batch, int len, int cv, int nsplit) {
+    if (batch < 0 || len < 0 || cv < 0 || nsplit < 2) return 0;
+    return (size_t)nsplit * batch * len * (cv + 2) * sizeof(float);
+}
+
 int ct_attention_tokens_f32(const float *q, const float *k, const float *v, const int *region, const int *rowmap, float *out,
-                            int batch, int len, int cv, float scale, void *stream) {
-    if (!q || !k || !v || !out || batch < 0 || len < 1 || (cv != 2 && cv != 128)) return CT_E_BADARG;
+                            int batch, int len, int cv, float scale, int nsplit, float *ws, size_t ws_bytes, void *stream) {
+    if (!q || !k || !v || !out || batch < 0 || len < 1 || (cv != 2 && cv != 128) || nsplit < 1 || nsplit > 64) return CT_E_BADARG;
+    if (nsplit > 1 && (!ws || ws_bytes < ct_attention_workspace_bytes(batch, len, cv, nsplit))) return CT_E_WORKSPACE;
     if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(out)) & 15) return CT_E_ALIGN;
     if (batch == 0) return CT_OK;
-    dim3 grid((len + 127) / 128, batch);
+    dim3 grid((len + 127) / 128, batch, nsplit);
     float *nostats = nullptr;
-    if (cv == 128) hipLaunchKernelGGL((ct::attention_tokens_kernel<128, 128>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, region, rowmap, out, nostats, len, scale);
-    else hipLaunchKernelGGL((ct::attention_tokens_kernel<128, 2>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, region, rowmap, out, nostats, len, scale);
+    if (cv == 128) hipLaunchKernelGGL((ct::attention_tokens_kernel<128, 128>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, region, rowmap, out, nostats, len, scale, ws);
+    else hipLaunchKernelGGL((ct::attention_tokens_kernel<128, 2>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, region, rowmap, out, nostats, len, scale, ws);
     CT_CHECK_LAUNCH();
+    if (nsplit > 1) {
+        const long long tokens = (long long)batch * len;
+        hipLaunchKernelGGL(ct::attention_combine_kernel, dim3((unsigned)((tokens * cv + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           ws, rowmap, out, tokens, cv, nsplit);
+        CT_CHECK_LAUNCH();
+    }
     return CT_OK;
 }
 
@@ -978,8 +1036,8 @@ int ct_attention_rows64_f32(const float *q, const float *k, const float *v, floa
     dim3 grid((len + 127) / 128, batch);
     const int *noreg = nullptr;
     if (v && (reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(out)) & 15) return CT_E_ALIGN;
-    if (v) hipLaunchKernelGGL((ct::attention_tokens_kernel<64, 96>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, noreg, noreg, out, stats, len, scale);
-    else hipLaunchKernelGGL((ct::attention_tokens_kernel<64, 0>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, noreg, noreg, out, stats, len, scale);
+    if (v) hipLaunchKernelGGL((ct::attention_tokens_kernel<64, 96>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, noreg, noreg, out, stats, len, scale, (float *)nullptr);
+    else hipLaunchKernelGGL((ct::attention_tokens_kernel<64, 0>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, noreg, noreg, out, stats, len, scale, (float *)nullptr);
     CT_CHECK_LAUNCH();
     return CT_OK;
 }

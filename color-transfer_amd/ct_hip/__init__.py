@@ -407,7 +407,9 @@ SIGNATURES.update({
     "ct_eltwise_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_f, _c_p]),
     "ct_linear_tokens_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p]),
     "ct_layernorm128_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_p]),
-    "ct_attention_tokens_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_p]),
+    "ct_attention_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int, _c_int, _c_int]),
+    "ct_attention_tokens_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_int, _c_p,
+                                         ctypes.c_size_t, _c_p]),
     "ct_attention_rows64_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_f, _c_p]),
     "ct_attention_colsum64_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_f, _c_p]),
     "ct_local_corr_softmax_f32": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
@@ -496,7 +498,7 @@ def layernorm128(x, gamma, beta, residual=None):
     return out
 
 
-def attention_tokens(q, k, v, region=None, scale=None, rowmap=None):
+def attention_tokens(q, k, v, region=None, scale=None, rowmap=None, nsplit=None):
     """q,k [B,L,128], v [B,L,128] or [B,L,2]; region int32 [B,L] or None -> [B,L,cv].
     With rowmap (int32 [B', L']): B' x L' attention problems whose token (b, i) is row rowmap[b, i] of the flattened
     q / k / v / out -- window partitions without copies; the result has v's shape."""
@@ -515,8 +517,16 @@ def attention_tokens(q, k, v, region=None, scale=None, rowmap=None):
     else:
         b, l, _ = q.shape
         out = torch.empty((b, l, cv), dtype=torch.float32, device=q.device)
+    if nsplit is None:
+        # key split so that ~2 workgroups per CU exist (global matching at 1/8 resolution launches only 56 otherwise)
+        wgs = b * ((l + 127) // 128)
+        nsplit = 1 if wgs >= 384 else max(1, min(8, 512 // max(wgs, 1), (l + 255) // 256))
+    ws, need = None, 0
+    if nsplit > 1:
+        need = lib().ct_attention_workspace_bytes(b, l, cv, nsplit)
+        ws = workspace(-2, 0, 0, q.device, need=need)
     check(lib().ct_attention_tokens_f32(_ptr(q), _ptr(k), _ptr(v), _opt(region), _opt(rowmap), _ptr(out), b, l, cv,
-                                        float(scale if scale is not None else c ** -0.5), _stream()))
+                                        float(scale if scale is not None else c ** -0.5), nsplit, _opt(ws), need, _stream()))
     return out
 
 

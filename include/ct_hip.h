@@ -216,9 +216,14 @@ int ct_layernorm128_f32(const float *x, const float *gamma, const float *beta, c
  *   matching.py:10-39; flow propagation, attention.py:199-216).  region: NULL, or int32 [batch][len] ids;
  *   pairs with different ids get the additive -100 of the shifted-window mask (utils.py:87-111).
  *   rowmap: NULL (token (b, i) is row b*len + i of q/k/v/out), or int32 [batch][len] row indices into q/k/v/out: the
- *   (shifted) window partition of attention.py:60-92,100-107 as a gather/scatter table instead of roll + permute.   */
+ *   (shifted) window partition of attention.py:60-92,100-107 as a gather/scatter table instead of roll + permute.
+ *   nsplit > 1: the keys are split over nsplit workgroups per query tile and merged by a second kernel (same result up
+ *   to float rounding); ws needs ct_attention_workspace_bytes(batch, len, cv, nsplit).  Use it when batch*len/128
+ *   workgroups cannot fill the 256 CUs.                                                                            */
+size_t ct_attention_workspace_bytes(int batch, int len, int cv, int nsplit);
 int ct_attention_tokens_f32(const float *q, const float *k, const float *v, const int *region, const int *rowmap,
-                            float *out, int batch, int len, int cv, float scale, void *stream);
+                            float *out, int batch, int len, int cv, float scale, int nsplit, float *ws,
+                            size_t ws_bytes, void *stream);
 /* Streaming parallax attention on 64-channel row tokens (pasmnet/attention.py:39-46, utils.py:30-35,123-125), for
  * image widths whose score tile does not fit LDS (ct_pam_* need w <= 1982) and as the faster path in general:
  *   ct_attention_rows64_f32 : out[b][i][0:96] = softmax_j(q_i.k_j*scale) v[b][j][0:96]   (v != NULL), and/or the row

@@ -95,8 +95,9 @@ def test_attention_tokens(hip, b, l, cv, masked):
         region = torch.randint(0, 4, (b, l), generator=G, dtype=torch.int32)
         scores = scores + torch.where(region[:, :, None] != region[:, None, :], -100.0, 0.0)
     ref = torch.matmul(torch.softmax(scores, dim=-1), v.double())
-    out = hip.attention_tokens(q.cuda(), k.cuda(), v.cuda(), region.cuda() if masked else None)
-    close(out, ref, "attention", atol=5e-5, rtol=1e-4)
+    for nsplit in (None, 1, 3, 8):                 # key split + merge kernel: same softmax
+        out = hip.attention_tokens(q.cuda(), k.cuda(), v.cuda(), region.cuda() if masked else None, nsplit=nsplit)
+        close(out, ref, "attention nsplit=%s" % nsplit, atol=5e-5, rtol=1e-4)
 
 
 @pytest.mark.parametrize("cv,shift", [(128, False), (128, True), (2, True)])
@@ -123,8 +124,9 @@ def test_attention_rowmap_is_window_partition(hip, cv, shift):
     ref = ref.view(b, splits, splits, wh, ww, cv).permute(0, 1, 3, 2, 4, 5).reshape(b, h, w, cv)
     if shift:
         ref = torch.roll(ref, shifts=(wh // 2, ww // 2), dims=(1, 2))
-    out = hip.attention_tokens(q.cuda(), k.cuda(), v.cuda(), region.cuda() if shift else None, rowmap=rowmap.cuda())
-    close(out, ref.reshape(b, h * w, cv), "window attention through rowmap", atol=5e-5, rtol=1e-4)
+    for nsplit in (1, 2):
+        out = hip.attention_tokens(q.cuda(), k.cuda(), v.cuda(), region.cuda() if shift else None, rowmap=rowmap.cuda(), nsplit=nsplit)
+        close(out, ref.reshape(b, h * w, cv), "window attention through rowmap, nsplit=%d" % nsplit, atol=5e-5, rtol=1e-4)
 
 
 def test_local_corr_kernels(hip):
