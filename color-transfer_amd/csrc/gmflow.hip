@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(const float *__r
     float num = 0.f, den = 0.f;
     for (int z = 0; z < nsplit; ++z) {
         const float m = p[z * zs + CV];
-        const float wgt = (m == -INFINITY) ? 0.f : expf(m - M);
+        const float wgt = (m == -INFINITY) ? 0.f : exp2f(m - M);   // the partial maxima are log2-domain scores
         num += wgt * p[z * zs + ch];
         den += wgt * p[z * zs + CV + 1];
     }
@@ -353,7 +353,9 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(const float *__r
 // q/k/v rows are fetched with 16-byte loads (a lane needs C/2 consecutive channels of one token row).
 // grid = (ceil(L/128), B); block = 4 waves.
 // =================================================================================================
-template <int C, int CV>
+constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+
+template <int C, int CV, bool MAP>
 __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                                const float *__restrict__ v, const int *__restrict__ region,
                                                                const int *__restrict__ rowmap, float *__restrict__ out,
@@ -380,15 +382,19 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
     const int qclamp = qlive ? qi : L - 1;
     // rowmap (optional): token (b, i) of this launch lives in row rowmap[b*L + i] of q / k / v / out -- the shifted-window
     // partition of attention.py:60-92 as an index table instead of roll + permute copies
-    auto row = [&](int i) -> size_t { return rowmap ? (size_t)rowmap[tb + i] : tb + i; };
+    auto row = [&](int i) -> size_t {
+        if constexpr (MAP) return (size_t)rowmap[tb + i];
+        else return tb + i;
+    };
     // B operand of S^T = K Q^T : lane (query nl, half hl) holds q[query][hl*C/2 + p], p < C/2
     float qb[CH];
+    const float qs = scale * kLog2e;   // scores live in the log2 domain: softmax through v_exp_f32 (2^x) directly
     {
         const float *qp = q + row(qclamp) * C + hl * CH;
 #pragma unroll
         for (int i = 0; i < CH / 4; ++i) {
             const float4 t = *reinterpret_cast<const float4 *>(qp + 4 * i);
-            qb[4 * i] = t.x * scale; qb[4 * i + 1] = t.y * scale; qb[4 * i + 2] = t.z * scale; qb[4 * i + 3] = t.w * scale;
+            qb[4 * i] = t.x * qs; qb[4 * i + 1] = t.y * qs; qb[4 * i + 2] = t.z * qs; qb[4 * i + 3] = t.w * qs;
         }
     }
     const int qreg = region ? region[tb + qclamp] : 0;
@@ -428,7 +434,7 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
             if (tid < 16) {   // 32 keys x 2 channels = 16 float4
                 const int key = 2 * tid;
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (rowmap) {
+                if constexpr (MAP) {
                     if (j0 + key < L) { const float2 u = *reinterpret_cast<const float2 *>(v + row(j0 + key) * 2); t.x = u.x; t.y = u.y; }
                     if (j0 + key + 1 < L) { const float2 u = *reinterpret_cast<const float2 *>(v + row(j0 + key + 1) * 2); t.z = u.x; t.w = u.y; }
                 } else if (j0 + key + 1 < L) t = *reinterpret_cast<const float4 *>(v + (tb + j0 + key) * 2);
@@ -482,37 +488,46 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
             fetch(j0 + 32);
             fetch_rows(j0 + 64);
         }
-        // ---- S^T tile: A = K rows (key nl) from LDS, B = Q ----
+        // ---- S^T tile: A = K rows (key nl) from LDS, B = Q.  LDS operand reads run one group ahead of the MFMAs that
+        //      consume them (a single wave per SIMD lives here: nothing else would hide the LDS latency) ----
         f32x16g s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
         const float *kp = Ks + nl * KLD + hl * CH;
+        float4 tc = *reinterpret_cast<const float4 *>(kp), tn = tc;
 #pragma unroll
         for (int i = 0; i < CH / 4; ++i) {
-            const float4 t = *reinterpret_cast<const float4 *>(kp + 4 * i);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(t.x, qb[4 * i], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(t.y, qb[4 * i + 1], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(t.z, qb[4 * i + 2], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(t.w, qb[4 * i + 3], s, 0, 0, 0);
+            if (i + 1 < CH / 4) tn = *reinterpret_cast<const float4 *>(kp + 4 * (i + 1));
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(tc.x, qb[4 * i], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(tc.y, qb[4 * i + 1], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(tc.z, qb[4 * i + 2], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(tc.w, qb[4 * i + 3], s, 0, 0, 0);
+            tc = tn;
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the LDS read of group i+1
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // the MFMAs of group i
         }
-        // lane: query nl; s[r] = score of key j0 + (r&3)+8(r>>2)+4hl
-        float mx = -INFINITY;
+        // lane: query nl; s[r] = log2-domain score of key j0 + (r&3)+8(r>>2)+4hl (q carries scale * log2(e))
+        if (region) {                                    // shifted-window mask, one uniform branch per tile
+            int rk[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kl = (r & 3) + 8 * (r >> 2) + 4 * hl;
-            float sv = s[r];
-            if (region) sv += (Rs[kl] != qreg) ? -100.0f : 0.0f;
-            sv = (j0 + kl < L) ? sv : -INFINITY;
-            s[r] = sv;
-            mx = fmaxf(mx, sv);
+            for (int r = 0; r < 16; ++r) rk[r] = Rs[(r & 3) + 8 * (r >> 2) + 4 * hl];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] += (rk[r] != qreg) ? -100.0f * kLog2e : 0.0f;
         }
+        if (j0 + 32 > L) {                               // ragged last tile
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = (j0 + (r & 3) + 8 * (r >> 2) + 4 * hl < L) ? s[r] : -INFINITY;
+        }
+        float mx = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));          // the other half of the keys of this query
-        const float m_new = fmaxf(m_run, mx);
-        const float corr = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+        const float m_new = fmaxf(m_run, mx);            // finite: key j0 exists and a mask only subtracts 100
+        const float corr = __builtin_amdgcn_exp2f(m_run - m_new);   // exp2(-inf) = 0 on the first tile
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float p = (s[r] == -INFINITY) ? 0.f : expf(s[r] - m_new);
+            const float p = __builtin_amdgcn_exp2f(s[r] - m_new);
             s[r] = p;
             psum += p;
         }
@@ -526,11 +541,22 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
                 for (int r = 0; r < 16; ++r) o[j][r] *= corr;
             // O^T[c][query] += sum_key V[key][c] P[key][query]: k-step r pairs the keys held by the two lane halves
             // in register r (keys kk and kk+4); A = V[key][channel nl of each 32-channel tile] from LDS
+            float vc[NVT], vn[NVT];
+#pragma unroll
+            for (int j = 0; j < NVT; ++j) vc[j] = Vs[(4 * hl) * VLD + nl + 32 * j];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float *vp = Vs + ((r & 3) + 8 * (r >> 2) + 4 * hl) * VLD + nl;
+                if (r + 1 < 16) {
+                    const float *vp = Vs + (((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * hl) * VLD + nl;
 #pragma unroll
-                for (int j = 0; j < NVT; ++j) o[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * j], s[r], o[j], 0, 0, 0);
+                    for (int j = 0; j < NVT; ++j) vn[j] = vp[32 * j];
+                }
+#pragma unroll
+                for (int j = 0; j < NVT; ++j) o[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[j], s[r], o[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NVT; ++j) vc[j] = vn[j];
+                __builtin_amdgcn_sched_group_barrier(0x100, (NVT + 1) / 2, 0);   // ds_read2_b32 pairs of step r+1
+                __builtin_amdgcn_sched_group_barrier(0x008, NVT, 0);             // the MFMAs of step r
             }
         } else if constexpr (CV == 2) {
             float ax = 0.f, ay = 0.f;
@@ -569,7 +595,7 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
     }
     const float inv = 1.0f / l_run;
     if (stats && qlive && hl == 0) {     // row statistics of the softmax (max, sum): used by the column-sum pass
-        stats[(tb + qi) * 2] = m_run;
+        stats[(tb + qi) * 2] = m_run * kLn2;   // natural-log units for attention_colsum_kernel
         stats[(tb + qi) * 2 + 1] = l_run;
     }
     if constexpr (CV >= 32) {
@@ -1016,8 +1042,10 @@ int ct_attention_tokens_f32(const float *q, const float *k, const float *v, cons
     if (batch == 0) return CT_OK;
     dim3 grid((len + 127) / 128, batch, nsplit);
     float *nostats = nullptr;
-    if (cv == 128) hipLaunchKernelGGL((ct::attention_tokens_kernel<128, 128>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, region, rowmap, out, nostats, len, scale, ws);
-    else hipLaunchKernelGGL((ct::attention_tokens_kernel<128, 2>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, region, rowmap, out, nostats, len, scale, ws);
+#define CT_ATT(CVV, MAPPED) hipLaunchKernelGGL((ct::attention_tokens_kernel<128, CVV, MAPPED>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, region, rowmap, out, nostats, len, scale, ws)
+    if (cv == 128) { if (rowmap) CT_ATT(128, true); else CT_ATT(128, false); }
+    else { if (rowmap) CT_ATT(2, true); else CT_ATT(2, false); }
+#undef CT_ATT
     CT_CHECK_LAUNCH();
     if (nsplit > 1) {
         const long long tokens = (long long)batch * len;
@@ -1036,8 +1064,8 @@ int ct_attention_rows64_f32(const float *q, const float *k, const float *v, floa
     dim3 grid((len + 127) / 128, batch);
     const int *noreg = nullptr;
     if (v && (reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(out)) & 15) return CT_E_ALIGN;
-    if (v) hipLaunchKernelGGL((ct::attention_tokens_kernel<64, 96>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, noreg, noreg, out, stats, len, scale, (float *)nullptr);
-    else hipLaunchKernelGGL((ct::attention_tokens_kernel<64, 0>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, noreg, noreg, out, stats, len, scale, (float *)nullptr);
+    if (v) hipLaunchKernelGGL((ct::attention_tokens_kernel<64, 96, false>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, noreg, noreg, out, stats, len, scale, (float *)nullptr);
+    else hipLaunchKernelGGL((ct::attention_tokens_kernel<64, 0, false>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, noreg, noreg, out, stats, len, scale, (float *)nullptr);
     CT_CHECK_LAUNCH();
     return CT_OK;
 }
