@@ -37,7 +37,11 @@ constexpr int kNumCUs = 256;    // MI355X
 //          registers (43 VGPRs) while the current one is multiplied, so HBM/L2 latency hides under the MFMAs
 // ---------------------------------------------------------------------------------------------
 
+// GEN = false: the DCMCS3DI instantiations, which only know LeakyReLU(0.01) -- the full switch in the epilogue costs
+// them 1.5 % (measured r01)
+template <bool GEN>
 __device__ __forceinline__ float conv_act(float v, int act) {
+    if (!GEN) return v > 0.f ? v : 0.01f * v;
     switch (act) {
         case 1: return v > 0.f ? v : 0.01f * v;
         case 2: return v > 0.f ? v : 0.f;
@@ -47,7 +51,7 @@ __device__ __forceinline__ float conv_act(float v, int act) {
     }
 }
 
-template <int KH, int KW, int MT, bool VEC>
+template <int KH, int KW, int MT, bool VEC, bool GEN>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles_x, int tiles_y, int n_tiles) {
     constexpr int PADY = KH / 2, PADX = KW / 2;
     constexpr bool HALO = (KW > 1);
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             float v = acc[q][m][r];
-                            if (a.act) v = conv_act(v, a.act);
+                            if (a.act) v = conv_act<GEN>(v, a.act);
                             if (a.clamp) v = fminf(fmaxf(v, 0.f), 1.f);
                             stg[((r & 3) + 8 * (r >> 2) + 4 * hl) * 32 + nl] = v;
                         }
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
                             for (int r = 0; r < 16; ++r) {
                                 const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
                                 float v = acc[q][m][r];
-                                if (a.act) v = conv_act(v, a.act);
+                                if (a.act) v = conv_act<GEN>(v, a.act);
                                 if (late_res && (full || co < cout_g)) v += res[(unsigned int)co * uplane + pix];
                                 if (a.clamp) v = fminf(fmaxf(v, 0.f), 1.f);
                                 if (full || co < cout_g) out[(unsigned int)co * uplane + pix] = v;
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, int tiles
 #endif
 }
 
-template <int KH, int KW, int MT>
+template <int KH, int KW, int MT, bool GEN>
 int launch_conv(const ConvArgs &a, int N, hipStream_t s) {
     constexpr int ROWS = kConvTH + KH - 1, TWP = (KW > 1) ? kConvTW + 8 : kConvTW;
     const size_t lds = (size_t)(kConvChunk * ROWS * TWP + 4 * 32 * 32) * sizeof(float);
@@ -409,8 +413,8 @@ int launch_conv(const ConvArgs &a, int N, hipStream_t s) {
     const long long n_tiles = (long long)tiles_x * tiles_y * N * a.groups;
     if (n_tiles > 0x7fffffffLL) return CT_E_BADARG;
     const int grid = n_tiles < 2 * kNumCUs ? (int)n_tiles : 2 * kNumCUs;   // persistent: two workgroups per CU
-    if (vec) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, MT, true>), dim3(grid), dim3(256), lds, s, a, tiles_x, tiles_y, (int)n_tiles);
-    else hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, MT, false>), dim3(grid), dim3(256), lds, s, a, tiles_x, tiles_y, (int)n_tiles);
+    if (vec) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, MT, true, GEN>), dim3(grid), dim3(256), lds, s, a, tiles_x, tiles_y, (int)n_tiles);
+    else hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, MT, false, GEN>), dim3(grid), dim3(256), lds, s, a, tiles_x, tiles_y, (int)n_tiles);
     CT_CHECK_LAUNCH();
     return CT_OK;
 }
@@ -418,10 +422,10 @@ int launch_conv(const ConvArgs &a, int N, hipStream_t s) {
 // Stride-1 "same" convolutions with 64-channel output groups (GMFlow's backbone / refinement convs, gmflow.hip).
 // Returns 1 when the geometry has no fast kernel (the caller then uses its generic one).
 int conv_fast(const ConvArgs &a, int N, int kh, int kw, hipStream_t s) {
-    if (kh == 3 && kw == 3) return launch_conv<3, 3, 2>(a, N, s);
-    if (kh == 1 && kw == 1) return launch_conv<1, 1, 2>(a, N, s);
-    if (kh == 1 && kw == 5) return launch_conv<1, 5, 2>(a, N, s);
-    if (kh == 5 && kw == 1) return launch_conv<5, 1, 2>(a, N, s);
+    if (kh == 3 && kw == 3) return launch_conv<3, 3, 2, true>(a, N, s);
+    if (kh == 1 && kw == 1) return launch_conv<1, 1, 2, true>(a, N, s);
+    if (kh == 1 && kw == 5) return launch_conv<1, 5, 2, true>(a, N, s);
+    if (kh == 5 && kw == 1) return launch_conv<5, 1, 2, true>(a, N, s);
     return 1;
 }
 
@@ -687,7 +691,7 @@ int ct_conv2d_f32(const float *in, const float *wp, const float *bias, const flo
                   int cin, int cout, int h, int w, int ksize, long long in_bstride, long long out_bstride,
                   long long res_bstride, int act, int clamp, void *stream) {
     if (!in || !wp || !bias || !out || n < 0 || cin < 1 || cout < 1 || cout > 64 || h < 0 || w < 0) return CT_E_BADARG;
-    if (ksize != 1 && ksize != 3) return CT_E_BADARG;
+    if ((ksize != 1 && ksize != 3) || (act != 0 && act != 1)) return CT_E_BADARG;
     if (n == 0 || h == 0 || w == 0) return CT_OK;
     ct::ConvArgs a;
     a.in = in; a.wp = wp; a.bias = bias; a.residual = residual; a.out = out;
@@ -696,8 +700,8 @@ int ct_conv2d_f32(const float *in, const float *wp, const float *bias, const flo
     a.act = act; a.clamp = clamp; a.groups = 1; a.prof = nullptr;
     hipStream_t s = (hipStream_t)stream;
     const int mt = cout > 32 ? 2 : 1;
-    if (ksize == 3) return mt == 2 ? ct::launch_conv<3, 3, 2>(a, n, s) : ct::launch_conv<3, 3, 1>(a, n, s);
-    return mt == 2 ? ct::launch_conv<1, 1, 2>(a, n, s) : ct::launch_conv<1, 1, 1>(a, n, s);
+    if (ksize == 3) return mt == 2 ? ct::launch_conv<3, 3, 2, false>(a, n, s) : ct::launch_conv<3, 3, 1, false>(a, n, s);
+    return mt == 2 ? ct::launch_conv<1, 1, 2, false>(a, n, s) : ct::launch_conv<1, 1, 1, false>(a, n, s);
 }
 
 #ifdef CT_CONV_PROFILE
@@ -709,7 +713,7 @@ int ct_conv2d_prof_f32(const float *in, const float *wp, const float *bias, cons
     a.cin = cin; a.cout = cout; a.H = h; a.W = w;
     a.in_bstride = (long long)cin * h * w; a.out_bstride = (long long)cout * h * w; a.res_bstride = a.out_bstride;
     a.act = 0; a.clamp = 0; a.groups = 1; a.prof = prof;
-    return ct::launch_conv<3, 3, 2>(a, n, (hipStream_t)stream);
+    return ct::launch_conv<3, 3, 2, false>(a, n, (hipStream_t)stream);
 }
 #endif
 

@@ -138,6 +138,59 @@ __global__ __launch_bounds__(256) void inorm_kernel(const float *__restrict__ x,
     }
 }
 
+// Large planes (the 1/2-resolution backbone stage: 128 planes of 115k pixels) cannot fill 256 CUs with one workgroup
+// per plane: split every plane over kInormSplit workgroups -- partial sums first (fixed order, no atomics), then each
+// workgroup normalises its own chunk.
+constexpr int kInormSplit = 16;
+
+__global__ __launch_bounds__(256) void inorm_partial_kernel(const float *__restrict__ x, int plane, double *__restrict__ part) {
+    __shared__ double red[8];
+    const int chunk = (((plane + kInormSplit - 1) / kInormSplit) + 3) & ~3;
+    const int i0 = blockIdx.y * chunk, i1 = (i0 + chunk < plane) ? i0 + chunk : plane;
+    const float *xp = x + (size_t)blockIdx.x * plane;
+    double s = 0.0, ss = 0.0;
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+        const double v = xp[i];
+        s += v;
+        ss += v * v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off, 64);
+        ss += __shfl_down(ss, off, 64);
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { red[wid] = s; red[4 + wid] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double *o = part + ((size_t)blockIdx.x * kInormSplit + blockIdx.y) * 2;
+        o[0] = red[0] + red[1] + red[2] + red[3];
+        o[1] = red[4] + red[5] + red[6] + red[7];
+    }
+}
+
+__global__ __launch_bounds__(256) void inorm_apply_kernel(const float *__restrict__ x, const float *__restrict__ skip,
+                                                          float *__restrict__ y, int plane, float eps, int mode,
+                                                          const double *__restrict__ part) {
+    const int chunk = (((plane + kInormSplit - 1) / kInormSplit) + 3) & ~3;
+    const int i0 = blockIdx.y * chunk, i1 = (i0 + chunk < plane) ? i0 + chunk : plane;
+    const double *pp = part + (size_t)blockIdx.x * kInormSplit * 2;
+    double ts = 0.0, tss = 0.0;
+#pragma unroll
+    for (int z = 0; z < kInormSplit; ++z) { ts += pp[2 * z]; tss += pp[2 * z + 1]; }
+    const double mean = ts / plane;
+    double var = tss / plane - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float fm = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const size_t base = (size_t)blockIdx.x * plane;
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+        float v = (x[base + i] - fm) * rstd;
+        if (mode >= 1) v = v > 0.f ? v : 0.f;
+        if (mode == 2) { v += skip[base + i]; v = v > 0.f ? v : 0.f; }
+        y[base + i] = v;
+    }
+}
+
 // =================================================================================================
 // Elementwise helpers
 //   op 0: y = a + b              op 1: y = a * b                  op 2: y = (1 - z) * h + z * q   (a=z, b=h, c=q)
@@ -181,9 +234,12 @@ __global__ void eltwise_kernel(const float *__restrict__ a, const float *__restr
 // =================================================================================================
 constexpr int kLinLd = 36;   // LDS row stride in floats
 
-__global__ __launch_bounds__(256) void linear_tokens_kernel(const float *__restrict__ x, const float *__restrict__ w,
-                                                            const float *__restrict__ bias, float *__restrict__ out,
-                                                            long long T, int K, int N, int act /*0 none, 6 gelu*/) {
+// x2 != null: the input row is the concatenation [x[t][0:K1] | x2[t][0:K-K1]] (K1 % 32 == 0) -- the
+// torch.cat([source, message]) in front of the FFN (transformer.py:131) without materialising it.
+__global__ __launch_bounds__(256) void linear_tokens_kernel(const float *__restrict__ x, const float *__restrict__ x2, int K1,
+                                                            const float *__restrict__ w, const float *__restrict__ bias,
+                                                            float *__restrict__ out, long long T, int K, int N,
+                                                            int act /*0 none, 6 gelu*/) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 128 * kLinLd];
     float *Xs = lds, *Ws = lds + 128 * kLinLd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, hl = lane >> 5;
@@ -193,20 +249,25 @@ __global__ __launch_bounds__(256) void linear_tokens_kernel(const float *__restr
 
     // staging: thread -> 4 (row, 16-byte column) slots of each operand tile
     const int srow = tid >> 3, sq = tid & 7;
-    const float *xg[4], *wg[4];
+    const float *wg[4];
+    long long xr[4];
+    const int K2 = K - K1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const long long tr = t0 + srow + 32 * i;
         const int nr = n0 + srow + 32 * i;
-        xg[i] = x + (tr < T ? tr : T - 1) * K + 4 * sq;
+        xr[i] = tr < T ? tr : T - 1;
         wg[i] = w + (size_t)(nr < N ? nr : N - 1) * K + 4 * sq;
     }
     float4 px[4], pw[4];
     auto fetch = [&](int kc) {
         const bool inb = (kc + 4 * sq) < K;    // K % 4 == 0: a float4 is in range or not at all
+        const bool second = kc >= K1;          // uniform: a 32-channel chunk never straddles the two sources
+        const float *xs = second ? x2 + (kc - K1) + 4 * sq : x + kc + 4 * sq;
+        const int ld = second ? K2 : K1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            px[i] = inb ? *reinterpret_cast<const float4 *>(xg[i] + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+            px[i] = inb ? *reinterpret_cast<const float4 *>(xs + xr[i] * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
             pw[i] = inb ? *reinterpret_cast<const float4 *>(wg[i] + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
@@ -990,9 +1051,25 @@ int ct_gconv2d_f32(const float *in, const float *wp, const float *bias, float *o
     return CT_OK;
 }
 
-int ct_instance_norm_f32(const float *x, const float *skip, float *y, int planes, int plane, float eps, int mode, void *stream) {
+size_t ct_instance_norm_workspace_bytes(int planes) {
+    return planes > 0 ? (size_t)planes * ct::kInormSplit * 2 * sizeof(double) : 0;
+}
+
+int ct_instance_norm_f32(const float *x, const float *skip, float *y, int planes, int plane, float eps, int mode, void *ws,
+                         size_t ws_bytes, void *stream) {
     if (!x || !y || planes < 0 || plane < 1 || (mode == 2 && !skip)) return CT_E_BADARG;
     if (planes == 0) return CT_OK;
+    if (ws && planes < 1024 && plane >= 16384) {   // few, large planes: split them (see inorm_partial_kernel)
+        if (ws_bytes < ct_instance_norm_workspace_bytes(planes)) return CT_E_WORKSPACE;
+        if (reinterpret_cast<uintptr_t>(ws) & 7) return CT_E_ALIGN;
+        dim3 grid(planes, ct::kInormSplit);
+        hipLaunchKernelGGL(ct::inorm_partial_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, plane, (double *)ws);
+        CT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(ct::inorm_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, skip, y, plane, eps, mode,
+                           (const double *)ws);
+        CT_CHECK_LAUNCH();
+        return CT_OK;
+    }
     hipLaunchKernelGGL(ct::inorm_kernel, dim3(planes), dim3(256), 0, (hipStream_t)stream, x, skip, y, plane, eps, mode);
     CT_CHECK_LAUNCH();
     return CT_OK;
@@ -1008,13 +1085,14 @@ int ct_eltwise_f32(const float *a, const float *b, const float *c, float *y, lon
     return CT_OK;
 }
 
-int ct_linear_tokens_f32(const float *x, const float *w, const float *bias, float *out, long long tokens, int k, int n, int act,
-                         void *stream) {
+int ct_linear_tokens_f32(const float *x, const float *x2, int k1, const float *w, const float *bias, float *out, long long tokens,
+                         int k, int n, int act, void *stream) {
     if (!x || !w || !out || tokens < 0 || k < 16 || (k % 16) || n < 1) return CT_E_BADARG;
-    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) return CT_E_ALIGN;
+    if (x2 ? (k1 < 32 || k1 >= k || (k1 % 32)) : (k1 != k)) return CT_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(x2)) & 15) return CT_E_ALIGN;
     if (tokens == 0) return CT_OK;
     dim3 grid((unsigned)((tokens + 127) / 128), (n + 127) / 128);
-    hipLaunchKernelGGL(ct::linear_tokens_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, out, tokens, k, n, act);
+    hipLaunchKernelGGL(ct::linear_tokens_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, x2, k1, w, bias, out, tokens, k, n, act);
     CT_CHECK_LAUNCH();
     return CT_OK;
 }

@@ -403,9 +403,10 @@ def pam_valid(q, k, want_att=False):
 _c_f = ctypes.c_float
 SIGNATURES.update({
     "ct_gconv2d_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 10 + [_c_ll, _c_ll, _c_int, _c_p]),
-    "ct_instance_norm_f32": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_f, _c_int, _c_p]),
+    "ct_instance_norm_workspace_bytes": (ctypes.c_size_t, [_c_int]),
+    "ct_instance_norm_f32": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_f, _c_int, _c_p, ctypes.c_size_t, _c_p]),
     "ct_eltwise_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_f, _c_p]),
-    "ct_linear_tokens_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p]),
+    "ct_linear_tokens_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p, ctypes.c_longlong, _c_int, _c_int, _c_int, _c_p]),
     "ct_layernorm128_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_p]),
     "ct_attention_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int, _c_int, _c_int]),
     "ct_attention_tokens_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_int, _c_p,
@@ -468,7 +469,9 @@ def instance_norm(x, mode=0, skip=None, eps=1e-5):
     _f32c(x, skip)
     n, c, h, w = x.shape
     y = torch.empty_like(x)
-    check(lib().ct_instance_norm_f32(_ptr(x), _opt(skip), _ptr(y), n * c, h * w, eps, mode, _stream()))
+    need = lib().ct_instance_norm_workspace_bytes(n * c)
+    ws = workspace(-3, 0, 0, x.device, need=need)
+    check(lib().ct_instance_norm_f32(_ptr(x), _opt(skip), _ptr(y), n * c, h * w, eps, mode, _ptr(ws), need, _stream()))
     return y
 
 
@@ -479,13 +482,17 @@ def eltwise(op, a, b=None, c=None, plane=1, chans=1, split=0, s0=1.0):
     return y
 
 
-def linear_tokens(x, weight, bias=None, act=ACT_NONE):
-    """x [..., K] channels-last tokens, weight [N, K] (PyTorch layout) -> [..., N]"""
-    _f32c(x, weight, bias)
-    k, n = x.shape[-1], weight.shape[0]
-    t = x.numel() // k
+def linear_tokens(x, weight, bias=None, act=ACT_NONE, x2=None):
+    """x [..., K1] channels-last tokens (optionally concatenated with x2 [..., K2] on the fly), weight [N, K1+K2]
+    (PyTorch layout) -> [..., N]"""
+    _f32c(x, weight, bias, x2)
+    k1, n = x.shape[-1], weight.shape[0]
+    k = k1 + (x2.shape[-1] if x2 is not None else 0)
+    if weight.shape[1] != k or (x2 is not None and x2.shape[:-1] != x.shape[:-1]):
+        raise CtHipError("linear_tokens: shape mismatch")
+    t = x.numel() // k1
     out = torch.empty(x.shape[:-1] + (n,), dtype=torch.float32, device=x.device)
-    check(lib().ct_linear_tokens_f32(_ptr(x), _ptr(weight), _opt(bias), _ptr(out), t, k, n, int(act), _stream()))
+    check(lib().ct_linear_tokens_f32(_ptr(x), _opt(x2), k1, _ptr(weight), _opt(bias), _ptr(out), t, k, n, int(act), _stream()))
     return out
 
 

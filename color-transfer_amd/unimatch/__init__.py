@@ -146,8 +146,8 @@ def _conv(m, x, act=ACT_NONE, stride=None, padding=None, weight=None):
     return ct_hip.gconv2d(x, wp, bp, w.shape[0], (w.shape[2], w.shape[3]), st, pd, act=act)
 
 
-def _lin(m, x, act=ACT_NONE):
-    return ct_hip.linear_tokens(x, m.weight.detach(), None if m.bias is None else m.bias.detach(), act=act)
+def _lin(m, x, act=ACT_NONE, x2=None):
+    return ct_hip.linear_tokens(x, m.weight.detach(), None if m.bias is None else m.bias.detach(), act=act, x2=x2)
 
 
 def _tokens(x):                                        # [B,C,H,W] -> [B,H*W,C]  (transformer.py:238-239)
@@ -267,7 +267,7 @@ class GMFlow(nn.Module):
         if m.no_ffn:
             return ct_hip.layernorm128(msg, g1, b1, residual=source)
         msg = ct_hip.layernorm128(msg, g1, b1)
-        x = _lin(m.mlp[2], _lin(m.mlp[0], torch.cat([source, msg], dim=-1).contiguous(), act=ACT_GELU))
+        x = _lin(m.mlp[2], _lin(m.mlp[0], source, act=ACT_GELU, x2=msg))      # mlp(cat([source, message])), no copy
         return ct_hip.layernorm128(x, m.norm2.weight.detach(), m.norm2.bias.detach(), residual=source)
 
     def _transformer(self, t0, t1, h, w, splits):                        # transformer.py:229-297

@@ -192,22 +192,28 @@ int ct_pam_valid_f32(const float *q, const float *k, float *valid, float *colsum
  *
  * ct_gconv2d_f32: Conv2d with any kernel / stride / padding / channel count (backbone.py:14-17,53,67;
  *   trident_conv.py:64-72; reg_refine.py:16-17,33-39,65-69,104-107; unimatch.py:59). act: 0 none, 1 LeakyReLU(0.01),
- *   2 ReLU, 3 sigmoid, 4 tanh.  wp: [kh*kw][ceil(cin/2)][2][64*ceil(cout/64)] (zero padded), bias padded likewise or NULL. */
+ *   2 ReLU, 3 sigmoid, 4 tanh.  wp: output channels in groups of 64, [ceil(cout/64)][kh*kw][ceil(cin/2)][2][64] (zero
+ *   padded); bias padded to 64*ceil(cout/64), or NULL.  Stride-1 "same" convolutions with a 3x3 / 1x1 / 1x5 / 5x1
+ *   kernel and a bias run on the LDS-tiled persistent kernel of ct_conv2d_f32, everything else on a generic one.  */
 int ct_gconv2d_f32(const float *in, const float *wp, const float *bias, float *out, int n, int cin,
                    int cout, int h, int w, int kh, int kw, int stride, int pad_h, int pad_w,
                    long long in_bstride, long long out_bstride, int act, void *stream);
 /* InstanceNorm2d(affine=False) over `planes` planes of `plane` elements (backbone.py:10,34-39):
- *   mode 0: IN(x)   1: relu(IN(x))   2: relu(skip + relu(IN(x)))                                                */
+ *   mode 0: IN(x)   1: relu(IN(x))   2: relu(skip + relu(IN(x))).  ws (nullable, 8-byte aligned,
+ *   ct_instance_norm_workspace_bytes(planes)): lets few large planes be split over several workgroups each.       */
+size_t ct_instance_norm_workspace_bytes(int planes);
 int ct_instance_norm_f32(const float *x, const float *skip, float *y, int planes, int plane, float eps,
-                         int mode, void *stream);
+                         int mode, void *ws, size_t ws_bytes, void *stream);
 /* elementwise: op 0 a+b, 1 a*b, 2 (1-a)*b + a*c (GRU update, reg_refine.py:47,55), 3 normalize_img (utils.py:26-34),
  *   4 a*s0, 5 tanh on channels < split / relu on the rest (unimatch.py:320-323)                                   */
 int ct_eltwise_f32(const float *a, const float *b, const float *c, float *y, long long n, int op,
                    int plane, int chans, int split, float s0, void *stream);
 /* nn.Linear on tokens: out[t][n] = act(x[t][:] . w[n][:] + bias[n]); w in PyTorch layout [n][k]; k % 16 == 0;
- *   act 0 none, 6 exact GELU (transformer.py:26-41; attention.py:181-182)                                          */
-int ct_linear_tokens_f32(const float *x, const float *w, const float *bias, float *out, long long tokens,
-                         int k, int n, int act, void *stream);
+ *   act 0 none, 6 exact GELU (transformer.py:26-41; attention.py:181-182).  x2 == NULL: x is [tokens][k], k1 == k.
+ *   x2 != NULL: the input row is [x[t][0:k1] | x2[t][0:k-k1]], k1 % 32 == 0 -- torch.cat([source, message], -1) in
+ *   front of the FFN (transformer.py:131) without materialising it.                                               */
+int ct_linear_tokens_f32(const float *x, const float *x2, int k1, const float *w, const float *bias, float *out,
+                         long long tokens, int k, int n, int act, void *stream);
 /* LayerNorm(128, eps 1e-5, affine) on tokens, out = residual + LN(x) when residual != NULL (transformer.py:139-147) */
 int ct_layernorm128_f32(const float *x, const float *gamma, const float *beta, const float *residual,
                         float *out, long long tokens, void *stream);

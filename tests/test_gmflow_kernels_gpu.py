@@ -54,6 +54,11 @@ def test_instance_norm(hip):
     close(hip.instance_norm(x.cuda(), 0), ref, "IN")
     close(hip.instance_norm(x.cuda(), 1), torch.relu(ref), "IN+relu")
     close(hip.instance_norm(x.cuda(), 2, skip.cuda()), torch.relu(skip.double() + torch.relu(ref)), "IN+relu+skip+relu")
+    # few large planes: every plane is split over 16 workgroups (partial sums + apply); ragged chunking (plane % 64 != 0)
+    x, skip = rnd(1, 3, 131, 127) * 2 - 0.5, rnd(1, 3, 131, 127)
+    ref = F.instance_norm(x.double(), eps=1e-5)
+    close(hip.instance_norm(x.cuda(), 0), ref, "IN split")
+    close(hip.instance_norm(x.cuda(), 2, skip.cuda()), torch.relu(skip.double() + torch.relu(ref)), "IN+relu+skip+relu split")
 
 
 def test_eltwise(hip):
@@ -77,6 +82,10 @@ def test_linear_tokens(hip, t, k, n, act):
         ref = F.gelu(ref)
     close(hip.linear_tokens(x.cuda(), w.cuda(), b.cuda(), act=act), ref, "linear")
     close(hip.linear_tokens(x.cuda(), w.cuda(), None, act=0), F.linear(x.double(), w.double()), "linear nobias")
+    if k >= 64:                                    # [x[:, :k1] | x[:, k1:]] from two tensors == linear on the concatenation
+        k1 = 32 * (k // 64)
+        xa, xb = x[:, :k1].contiguous().cuda(), x[:, k1:].contiguous().cuda()
+        close(hip.linear_tokens(xa, w.cuda(), b.cuda(), act=act, x2=xb), ref, "linear on a two-source row")
 
 
 def test_layernorm(hip):
