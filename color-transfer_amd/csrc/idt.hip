@@ -70,54 +70,95 @@ static IdtLayout idt_layout(void *ws, int batch, int n_iter, int bins) {
 // A6 (initial): min/max of r_it @ x for it in [it0, it0 + n_rot) ; `which` = 0 target, 1 reference
 // grid = (G, batch)
 // -------------------------------------------------------------------------------------------
+// One sweep serves up to four rotations: 4 pixels per lane come in as three 16-byte loads, the 3x3 rotations sit in
+// scalar registers, and min/max are float64 v_min/v_max (a 64-bit integer max is a compare + two selects); the
+// order-preserving keys that the integer atomicMax needs are built once per lane at the end.  A non-finite projection
+// poisons the range (NaN), as np.histogram's range check does in the reference.
 template <typename T, int MAXROT>
 __global__ __launch_bounds__(kIdtBlock) void idt_minmax_kernel(const T *__restrict__ img, int64_t n, const double *__restrict__ rot,
                                                                int n_iter, int it0, int n_rot, int which,
                                                                unsigned long long *__restrict__ mm) {
-    __shared__ unsigned long long lds[4 * 6];
+    constexpr int RG = 4;               // rotations per sweep
+    __shared__ unsigned long long lds[4 * 6 * RG];
     const int b = blockIdx.y;
     const T *p = img + (size_t)b * n * 3;
-    for (int q = 0; q < n_rot; ++q) {   // n_rot <= 8 in practice; one sweep per rotation keeps registers low
-        const int it = it0 + q;
-        double r[9];
+    const bool vec = (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+    const int64_t n_chunks = n >> 2;
+    for (int q0 = 0; q0 < n_rot; q0 += RG) {
+        const int nq = (n_rot - q0) < RG ? (n_rot - q0) : RG;
+        double r[RG][9];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) r[i] = rot[((size_t)b * n_iter + it) * 9 + i];
-        unsigned long long k[6] = {0, 0, 0, 0, 0, 0};
-        for (int64_t i = (int64_t)blockIdx.x * kIdtBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kIdtBlock) {
-            const double x0 = (double)p[3 * i], x1 = (double)p[3 * i + 1], x2 = (double)p[3 * i + 2];
+        for (int q = 0; q < RG; ++q)
+#pragma unroll
+            for (int i = 0; i < 9; ++i) r[q][i] = rot[((size_t)b * n_iter + it0 + q0 + (q < nq ? q : 0)) * 9 + i];
+        double mn[RG][3], mx[RG][3], bad = 0.0;
+#pragma unroll
+        for (int q = 0; q < RG; ++q)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { mn[q][j] = INFINITY; mx[q][j] = -INFINITY; }
+        auto pixel = [&](double x0, double x1, double x2) {
+#pragma unroll
+            for (int q = 0; q < RG; ++q)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const double d = proj(r[q] + 3 * j, x0, x1, x2);
+                    mn[q][j] = fmin(mn[q][j], d);
+                    mx[q][j] = fmax(mx[q][j], d);
+                    bad = fma(d, 0.0, bad);          // stays 0 unless d is NaN or infinite
+                }
+        };
+        for (int64_t c = (int64_t)blockIdx.x * kIdtBlock + threadIdx.x; c < n_chunks; c += (int64_t)gridDim.x * kIdtBlock) {
+            Raw12<T> raw;
+            load12_raw<T>(p + c * 12, vec, raw);
+            double v[12];
+            unpack12<T>(raw, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pixel(v[3 * e], v[3 * e + 1], v[3 * e + 2]);
+        }
+        if (blockIdx.x == 0) {          // ragged tail: n % 4 pixels
+            const int64_t i = (n_chunks << 2) + threadIdx.x;
+            if (threadIdx.x < 3 && i < n) pixel((double)p[3 * i], (double)p[3 * i + 1], (double)p[3 * i + 2]);
+        }
+        // keys: k[q][2j] = key(-min), k[q][2j+1] = key(max); a poisoned lane publishes NaN for all of them
+        unsigned long long k[RG][6];
+        const bool poisoned = !(bad == 0.0);
+        const unsigned long long knan = f64_key(__longlong_as_double(0x7ff8000000000000ll));
+#pragma unroll
+        for (int q = 0; q < RG; ++q)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const double d = proj(r + 3 * j, x0, x1, x2);
-                const unsigned long long kn = f64_key(-d), kx = f64_key(d);
-                k[2 * j] = kn > k[2 * j] ? kn : k[2 * j];
-                k[2 * j + 1] = kx > k[2 * j + 1] ? kx : k[2 * j + 1];
+                k[q][2 * j] = poisoned ? knan : f64_key(-mn[q][j]);
+                k[q][2 * j + 1] = poisoned ? knan : f64_key(mx[q][j]);
             }
-        }
-        // mm[b][it][j][which*2 + {0: max(-d), 1: max(d)}]: gather the 6 keys into that layout
-        unsigned long long *dst = mm + (((size_t)b * n_iter + it) * 3) * 4;
-        // reorder: k = {j0min,j0max,j1min,j1max,j2min,j2max} -> dst[j*4 + which*2 + m]
-        __syncthreads();
 #pragma unroll
         for (int off = kWave / 2; off > 0; off >>= 1) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const unsigned long long o = __shfl_down(k[i], off, kWave);
-                k[i] = o > k[i] ? o : k[i];
-            }
+            for (int q = 0; q < RG; ++q)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const unsigned long long o = __shfl_down(k[q][i], off, kWave);
+                    k[q][i] = o > k[q][i] ? o : k[q][i];
+                }
         }
         const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x >> 6;
+        __syncthreads();                // the previous group's readers are done with lds
         if (lane == 0) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) lds[wid * 6 + i] = k[i];
+            for (int q = 0; q < RG; ++q)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) lds[(wid * RG + q) * 6 + i] = k[q][i];
         }
         __syncthreads();
-        if (threadIdx.x < 6) {
-            unsigned long long m = lds[threadIdx.x];
+        if (threadIdx.x < 6 * nq) {
+            const int q = threadIdx.x / 6, i = threadIdx.x - 6 * q;
+            unsigned long long m = lds[q * 6 + i];
             for (int w = 1; w < kIdtBlock / kWave; ++w) {
-                const unsigned long long o = lds[w * 6 + threadIdx.x];
+                const unsigned long long o = lds[(w * RG + q) * 6 + i];
                 m = o > m ? o : m;
             }
-            const int j = threadIdx.x >> 1, mmx = threadIdx.x & 1;
+            // mm[b][it][j][which*2 + {0: max(-d), 1: max(d)}]
+            unsigned long long *dst = mm + (((size_t)b * n_iter + it0 + q0 + q) * 3) * 4;
+            const int j = i >> 1, mmx = i & 1;
             atomicMax(dst + j * 4 + which * 2 + mmx, m);
         }
     }
