@@ -190,17 +190,14 @@ __device__ __forceinline__ int idt_bin(double x, int bins, double lo, double hi,
 }
 
 // -------------------------------------------------------------------------------------------
-// A8 part 1: publish (lo, hi, step, scale) of iteration `it` for the three axes. grid = batch, 64 threads
+// A8 part 1: (lo, hi, step, scale) of iteration `it`, axis j, from the min/max keys.  Every consumer evaluates this
+// itself (same arithmetic => same bits) instead of waiting for a one-workgroup kernel to publish them.
 // -------------------------------------------------------------------------------------------
-__global__ void idt_params_kernel(const unsigned long long *__restrict__ mm, double *__restrict__ par, int n_iter, int it,
-                                  int bins) {
-    const int b = blockIdx.x, j = threadIdx.x;
-    if (j < 3) {
-        double lo, hi;
-        idt_range(mm + (((size_t)b * n_iter + it) * 3) * 4, j, lo, hi);
-        double *o = par + (((size_t)b * n_iter + it) * 3 + j) * 4;
-        o[0] = lo; o[1] = hi; o[2] = (hi - lo) / (double)bins; o[3] = (double)bins / (hi - lo);
-    }
+__device__ __forceinline__ void idt_params(const unsigned long long *__restrict__ mm, int b, int n_iter, int it, int j, int bins,
+                                           double &lo, double &hi, double &step, double &scale) {
+    idt_range(mm + (((size_t)b * n_iter + it) * 3) * 4, j, lo, hi);
+    step = (hi - lo) / (double)bins;
+    scale = (double)bins / (hi - lo);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -209,7 +206,7 @@ __global__ void idt_params_kernel(const unsigned long long *__restrict__ mm, dou
 template <typename TT, typename TR>
 __global__ __launch_bounds__(kIdtHistBlock) void idt_hist_kernel(const TT *__restrict__ tgt, int64_t n_t, const TR *__restrict__ ref,
                                                              int64_t n_r, const double *__restrict__ rot,
-                                                             const double *__restrict__ par, int n_iter, int it, int bins,
+                                                             const unsigned long long *__restrict__ mm, int n_iter, int it, int bins,
                                                              unsigned int *__restrict__ hist, unsigned short *__restrict__ binidx) {
     extern __shared__ unsigned int lh[];  // [2][3][bins]
     const int b = blockIdx.y;
@@ -219,8 +216,7 @@ __global__ __launch_bounds__(kIdtHistBlock) void idt_hist_kernel(const TT *__res
     for (int i = 0; i < 9; ++i) r[i] = rot[((size_t)b * n_iter + it) * 9 + i];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const double *q = par + (((size_t)b * n_iter + it) * 3 + j) * 4;
-        lo[j] = q[0]; hi[j] = q[1]; step[j] = q[2]; scale[j] = q[3];
+        idt_params(mm, b, n_iter, it, j, bins, lo[j], hi[j], step[j], scale[j]);
     }
     __syncthreads();
     const int64_t stride = (int64_t)gridDim.x * kIdtHistBlock;
@@ -254,15 +250,20 @@ __global__ __launch_bounds__(kIdtHistBlock) void idt_hist_kernel(const TT *__res
 // -------------------------------------------------------------------------------------------
 // A8 part 2: cumulative histograms -> LUT f and its slopes. grid = (3, batch); dynamic LDS
 // -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kIdtBlock) void idt_lut_kernel(const unsigned int *__restrict__ hist, const double *__restrict__ par,
-                                                            int n_iter, int it, int bins, double *__restrict__ lut) {
+__global__ __launch_bounds__(kIdtBlock) void idt_lut_kernel(const unsigned int *__restrict__ hist, const unsigned long long *__restrict__ mm,
+                                                            double *__restrict__ par, int n_iter, int it, int bins,
+                                                            double *__restrict__ lut) {
     extern __shared__ double sm[];  // cp0[bins], cp1[bins], f[bins]
     double *cp0 = sm, *cp1 = sm + bins, *f = sm + 2 * bins;
     const int j = blockIdx.x, b = blockIdx.y;
     const unsigned int *h0 = hist + (((size_t)b * n_iter + it) * 6 + j) * bins;
     const unsigned int *h1 = hist + (((size_t)b * n_iter + it) * 6 + 3 + j) * bins;
-    const double *q = par + (((size_t)b * n_iter + it) * 3 + j) * 4;
-    const double lo = q[0], hi = q[1], step = q[2];
+    double lo, hi, step, scale;
+    idt_params(mm, b, n_iter, it, j, bins, lo, hi, step, scale);
+    if (threadIdx.x == 0) {             // published for the debug dump (ct_idt_debug.par)
+        double *q = par + (((size_t)b * n_iter + it) * 3 + j) * 4;
+        q[0] = lo; q[1] = hi; q[2] = step; q[3] = scale;
+    }
     // exact integer prefix sums of both histograms: each thread owns a contiguous segment (<= 4 bins for
     // bins <= 1024), a Hillis-Steele scan over the 256 segment totals in LDS, then the segment is re-walked
     __shared__ unsigned long long seg[2][kIdtBlock];
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(kIdtBlock) void idt_lut_kernel(const unsigned int *
 template <typename TT>
 __global__ __launch_bounds__(kIdtBlock) void idt_apply_kernel(const TT *__restrict__ tgt, double *__restrict__ out, int64_t n_t,
                                                               const double *__restrict__ rot, const double *__restrict__ rinv,
-                                                              const double *__restrict__ par, const double *__restrict__ lut,
+                                                              const double *__restrict__ lut,
                                                               int n_iter, int it, int bins, int round_f32,
                                                               unsigned long long *__restrict__ mm) {
     extern __shared__ double2 sl[];  // [3][bins] (f, slope)
@@ -359,8 +360,7 @@ __global__ __launch_bounds__(kIdtBlock) void idt_apply_kernel(const TT *__restri
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const double *q = par + (((size_t)b * n_iter + it) * 3 + j) * 4;
-        lo[j] = q[0]; hi[j] = q[1]; step[j] = q[2]; scale[j] = q[3];
+        idt_params(mm, b, n_iter, it, j, bins, lo[j], hi[j], step[j], scale[j]);
     }
     __syncthreads();
     unsigned long long key[6] = {0, 0, 0, 0, 0, 0};
@@ -467,28 +467,26 @@ static int idt_impl(const T *target, int64_t n_t, const T *reference, int64_t n_
     int gh = idt_grid((n_t > n_r ? n_t : n_r) / 4 + 1, batch);
     { int cap = 1024 / batch; cap = cap > 512 ? 512 : (cap < 64 ? 64 : cap); if (gh > cap) gh = cap; }   // per pair
     for (int it = 0; it < n_iter; ++it) {
-        hipLaunchKernelGGL(idt_params_kernel, dim3(batch), dim3(64), 0, s, l.mm, l.par, n_iter, it, bins);
-        CT_CHECK_LAUNCH();
         unsigned short *bi = (dbg && dbg->binidx) ? dbg->binidx : nullptr;
         if (it == 0) {
             hipLaunchKernelGGL((idt_hist_kernel<T, T>), dim3(gh, batch), dim3(kIdtHistBlock), 6 * bins * sizeof(unsigned int), s,
-                               target, n_t, reference, n_r, rot, l.par, n_iter, it, bins, l.hist, bi);
+                               target, n_t, reference, n_r, rot, l.mm, n_iter, it, bins, l.hist, bi);
         } else {
             hipLaunchKernelGGL((idt_hist_kernel<double, T>), dim3(gh, batch), dim3(kIdtHistBlock),
-                               6 * bins * sizeof(unsigned int), s, (const double *)out, n_t, reference, n_r, rot, l.par,
+                               6 * bins * sizeof(unsigned int), s, (const double *)out, n_t, reference, n_r, rot, l.mm,
                                n_iter, it, bins, l.hist, bi);
         }
         CT_CHECK_LAUNCH();
-        hipLaunchKernelGGL(idt_lut_kernel, dim3(3, batch), dim3(kIdtBlock), 3 * bins * sizeof(double), s, l.hist, l.par,
-                           n_iter, it, bins, l.lut);
+        hipLaunchKernelGGL(idt_lut_kernel, dim3(3, batch), dim3(kIdtBlock), 3 * bins * sizeof(double), s, l.hist, l.mm,
+                           l.par, n_iter, it, bins, l.lut);
         CT_CHECK_LAUNCH();
         const int rf = (round_dr_f32 && it == 0) ? 1 : 0;
         if (it == 0) {
             hipLaunchKernelGGL((idt_apply_kernel<T>), dim3(gt, batch), dim3(kIdtBlock), 3 * bins * sizeof(double2), s, target,
-                               out, n_t, rot, rinv, l.par, l.lut, n_iter, it, bins, rf, l.mm);
+                               out, n_t, rot, rinv, l.lut, n_iter, it, bins, rf, l.mm);
         } else {
             hipLaunchKernelGGL((idt_apply_kernel<double>), dim3(gt, batch), dim3(kIdtBlock), 3 * bins * sizeof(double2), s,
-                               (const double *)out, out, n_t, rot, rinv, l.par, l.lut, n_iter, it, bins, rf, l.mm);
+                               (const double *)out, out, n_t, rot, rinv, l.lut, n_iter, it, bins, rf, l.mm);
         }
         CT_CHECK_LAUNCH();
     }
