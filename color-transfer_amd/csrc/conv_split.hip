@@ -1,0 +1,402 @@
+// conv_split.hip -- the stride-1 convolutions of cnn.hip on the bf16 matrix pipe with float32-grade accuracy.
+//
+// v_mfma_f32_32x32x2_f32 (cnn.hip) runs at 1/16 of the bf16 MFMA rate on gfx950.  Here every float32 operand is split
+// into three bf16 pieces, x = hi + mid + lo (8 + 8 + 8 mantissa bits, each difference exact in float32), and a product
+// is evaluated as the six partial products whose weight is >= 2^-16 of the leading one
+//     a*b ~= a_lo*b_hi + a_hi*b_lo + a_mid*b_mid + a_mid*b_hi + a_hi*b_mid + a_hi*b_hi        (float32 accumulation)
+// -- what is dropped (mid*lo, lo*mid, lo*lo) is <= 2^-23 relative, the size of one float32 rounding.  Six
+// v_mfma_f32_32x32x16_bf16 (32 cycles each, K = 16) replace eight 32x32x2 f32 MFMAs (64 cycles each): 2.67x the
+// throughput at the same accuracy class (NOT bitwise the fmaf chain of the f32 kernel; parity bars are unchanged).
+//
+// Same implicit GEMM as conv_mfma_kernel: M = 64 output channels (A = weights, pre-split on the host, streamed from
+// L1/L2 into registers), N = 32 consecutive pixels of a row (B from an LDS halo tile), persistent workgroups walking
+// 8x32-pixel tiles, 16 input channels per stage (= one bf16 K step per tap).  The float32 NCHW input is split while it
+// is staged: a thread fetches 8 channels x 4 pixels with 16-byte loads, converts in registers and writes the LDS tile
+// [piece][row][k-half][column][8 channels] so that an MFMA B fragment (8 consecutive channels of one pixel) is one
+// conflict-free 16-byte read.  Epilogue (bias, activation, ResB skip, clamp, 16-byte stores through a per-wave LDS
+// transpose) as in cnn.hip.  Requires W % 4 == 0 and 16-byte aligned tensors; other cases stay on the f32 kernel.
+#include "ct_common.h"
+#include "ct_conv.h"
+
+namespace ct {
+
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kSpTH = 8;      // output rows per workgroup (two per wave)
+constexpr int kSpTW = 32;     // output columns per workgroup (= MFMA N)
+constexpr int kSpKC = 16;     // input channels per stage (= MFMA K)
+constexpr int kSpCUs = 256;
+
+template <bool GEN>
+__device__ __forceinline__ float split_act(float v, int act) {
+    if (!GEN) return v > 0.f ? v : 0.01f * v;
+    switch (act) {
+        case 1: return v > 0.f ? v : 0.01f * v;
+        case 2: return v > 0.f ? v : 0.f;
+        case 3: return 1.0f / (1.0f + expf(-v));
+        case 4: return tanhf(v);
+        default: return v;
+    }
+}
+
+// x -> (hi, mid, lo) bf16 bit patterns; hi + mid + lo == x up to 2^-24 relative.  Infinities keep mid = lo = 0.
+__device__ __forceinline__ void split3(float x, unsigned int &h, unsigned int &m, unsigned int &l) {
+    const __bf16 bh = (__bf16)x;
+    float r1 = x - (float)bh;
+    r1 = (r1 == r1) ? r1 : 0.f;
+    const __bf16 bm = (__bf16)r1;
+    const float r2 = r1 - (float)bm;
+    const __bf16 bl = (__bf16)r2;
+    h = __builtin_bit_cast(unsigned short, bh);
+    m = __builtin_bit_cast(unsigned short, bm);
+    l = __builtin_bit_cast(unsigned short, bl);
+}
+
+// wp : bf16 bit patterns [group][chunk16][tap][piece][m][lane = 32*khalf + cout%32][8 channels]   (host: pack_conv_weight_split)
+template <int KH, int KW, bool GEN>
+__global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tiles_x, int tiles_y, int n_tiles) {
+    constexpr int PADY = KH / 2, PADX = KW / 2;
+    constexpr bool HALO = (KW > 1);
+    constexpr int ROWS = kSpTH + KH - 1;
+    constexpr int TWP = HALO ? kSpTW + 8 : kSpTW;   // LDS row = image columns [x0-4, x0+36)
+    constexpr int COL0 = HALO ? 4 : 0;
+    constexpr int PSZ = ROWS * 2 * TWP;                // 16-byte entries per piece
+    constexpr int NU = 2 * ROWS * 8;                   // (k-half, row, 4-column group) units of 8 channels x 4 pixels
+    constexpr int HC = KW - 1;
+    constexpr int NE = kSpKC * ROWS * HC;              // halo scalars per stage
+    constexpr int PFE = (NE + 255) / 256;
+    constexpr int MT = 2, COUTP = 64, RPW = kSpTH / 4, TAPS = KH * KW;
+    static_assert(NU <= 256, "tile geometry");
+    extern __shared__ uint4 smem16[];
+    uint4 *tin = smem16;                                // [3][ROWS][2][TWP]
+    float *stg = reinterpret_cast<float *>(smem16 + 3 * PSZ) + (threadIdx.x >> 6) * (32 * 32);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, hl = lane >> 5;
+    const size_t plane = (size_t)a.H * a.W;
+    const unsigned int uplane = (unsigned int)plane;
+    const int n_chunks = (a.cin + kSpKC - 1) / kSpKC;
+    const int my_tiles = (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int n_stages = my_tiles * n_chunks;
+    if (n_stages == 0) return;
+
+    // ---- staging roles (fixed per thread) ----
+    const bool unit = tid < NU;
+    const int u_h = tid / (ROWS * 8), u_rem = tid - u_h * (ROWS * 8), u_row = u_rem >> 3, u_g = u_rem & 7;
+    float4 pf4[8];
+    float pfe[PFE > 0 ? PFE : 1];
+    auto fetch_tile = [&](int stage) {
+        const int k = stage / n_chunks, chunk = stage - k * n_chunks;
+        const int t = (blockIdx.x + k * gridDim.x) / a.groups;
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
+        const int x0 = tx * kSpTW, y0 = ty * kSpTH, c0 = chunk * kSpKC;
+        const float *in = a.in + (size_t)n * a.in_bstride + (size_t)c0 * plane;
+        if (unit) {
+            const int gy = y0 + u_row - PADY, gx = x0 + 4 * u_g;
+            const bool ok = gy >= 0 && gy < a.H && gx < a.W;          // W % 4 == 0: all four columns or none
+            const unsigned int off = (unsigned int)(gy * a.W + gx);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = 8 * u_h + j;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok && c0 + c < a.cin) v = *reinterpret_cast<const float4 *>(in + (unsigned int)c * uplane + off);
+                pf4[j] = v;
+            }
+        }
+        if (HALO) {
+#pragma unroll
+            for (int j = 0; j < PFE; ++j) {
+                const int e = (255 - tid) + j * 256;              // the threads without a unit take the halo first
+                const int c = e / (ROWS * HC), rem = e - c * (ROWS * HC);
+                const int yy = rem / HC, side = rem - yy * HC;
+                const int gy = y0 + yy - PADY, gx = side < PADX ? x0 - PADX + side : x0 + kSpTW + side - PADX;
+                float v = 0.f;
+                if (e < NE && c0 + c < a.cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                    v = in[(unsigned int)c * uplane + (unsigned int)(gy * a.W + gx)];
+                pfe[j] = v;
+            }
+        }
+    };
+    auto store_tile = [&]() {
+        if (unit) {
+            uint4 *dst = tin + (u_row * 2 + u_h) * TWP + COL0 + 4 * u_g;
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                unsigned int hw[4], mw[4], lw[4];
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) {
+                    const float4 v0 = pf4[2 * jp], v1 = pf4[2 * jp + 1];
+                    const float x0 = px == 0 ? v0.x : px == 1 ? v0.y : px == 2 ? v0.z : v0.w;
+                    const float x1 = px == 0 ? v1.x : px == 1 ? v1.y : px == 2 ? v1.z : v1.w;
+                    unsigned int h0, m0, l0, h1, m1, l1;
+                    split3(x0, h0, m0, l0);
+                    split3(x1, h1, m1, l1);
+                    hw[jp] = h0 | (h1 << 16); mw[jp] = m0 | (m1 << 16); lw[jp] = l0 | (l1 << 16);
+                }
+                dst[px] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+                dst[PSZ + px] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
+                dst[2 * PSZ + px] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+            }
+        }
+        if (HALO) {
+            unsigned short *t16 = reinterpret_cast<unsigned short *>(tin);
+#pragma unroll
+            for (int j = 0; j < PFE; ++j) {
+                const int e = (255 - tid) + j * 256;
+                const int c = e / (ROWS * HC), rem = e - c * (ROWS * HC);
+                const int yy = rem / HC, side = rem - yy * HC;
+                const int col = side < PADX ? COL0 - PADX + side : COL0 + kSpTW + side - PADX;
+                if (e < NE) {
+                    unsigned int h, m, l;
+                    split3(pfe[j], h, m, l);
+                    const int idx = ((yy * 2 + (c >> 3)) * TWP + col) * 8 + (c & 7);
+                    t16[idx] = (unsigned short)h;
+                    t16[PSZ * 8 + idx] = (unsigned short)m;
+                    t16[2 * PSZ * 8 + idx] = (unsigned short)l;
+                }
+            }
+        }
+    };
+    // ---- A operand: weights of one (tap, chunk): [piece][m] 16-byte fragments, coalesced 1 KiB per (piece, m) ----
+    const uint4 *wp16 = reinterpret_cast<const uint4 *>(a.wp);
+    auto load_w = [&](int grp, int chunk, int tap, uint4 (&w)[3][MT]) {
+        const uint4 *src = wp16 + ((((size_t)grp * n_chunks + chunk) * TAPS + tap) * 3 * MT) * 64 + lane;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) w[p][m] = src[(p * MT + m) * 64];
+    };
+
+    f32x16s acc[RPW][MT];
+    uint4 wa[3][MT], wb[3][MT];
+    // phase stagger of the two co-resident workgroups (see conv_mfma_kernel)
+    if (my_tiles >= 2) {
+        const unsigned int hw_wave_slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | ((4 - 1) << 11));   // HW_ID[3:0]
+        if (hw_wave_slot & 1) {
+            const int half_tile_cycles = n_chunks * TAPS * RPW * MT * 6 * 32 / 2;
+            for (int c = 0; c < half_tile_cycles; c += 64 * 64) __builtin_amdgcn_s_sleep(64);
+        }
+    }
+    const bool res_in_acc = (a.residual != nullptr) && (a.act == 0);
+    auto init_acc = [&](int k) {   // raw float4 rows of the skip tensor (or zeros); finish_acc() re-lays them out
+        const int tg = blockIdx.x + k * gridDim.x, t = tg / a.groups, grp = tg - t * a.groups;
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
+        const float *__restrict__ res = res_in_acc ? a.residual + (size_t)n * a.res_bstride + (size_t)grp * COUTP * plane : nullptr;
+        const int cout_g = a.cout - grp * COUTP;
+        const int x4 = tx * kSpTW + 4 * (lane & 7);
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            const int y = ty * kSpTH + wave * RPW + q;
+            const bool inb = res_in_acc && (y < a.H) && (x4 < a.W);
+            const unsigned int pix = (unsigned int)(y * a.W + x4);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int co = m * 32 + (lane >> 3) + 8 * j;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (inb && co < cout_g) v = *reinterpret_cast<const float4 *>(res + (unsigned int)co * uplane + pix);
+                    acc[q][m][4 * j + 0] = v.x; acc[q][m][4 * j + 1] = v.y;
+                    acc[q][m][4 * j + 2] = v.z; acc[q][m][4 * j + 3] = v.w;
+                }
+        }
+    };
+    auto finish_acc = [&]() {
+        if (!res_in_acc) return;      // zeros need no re-layout
+#pragma unroll
+        for (int q = 0; q < RPW; ++q)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<float4 *>(stg + ((lane >> 3) + 8 * j) * 32 + 4 * (lane & 7)) =
+                        make_float4(acc[q][m][4 * j], acc[q][m][4 * j + 1], acc[q][m][4 * j + 2], acc[q][m][4 * j + 3]);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][m][r] = stg[((r & 3) + 8 * (r >> 2) + 4 * hl) * 32 + nl];
+                __builtin_amdgcn_wave_barrier();
+            }
+    };
+
+    load_w((int)blockIdx.x % a.groups, 0, 0, wa);
+    fetch_tile(0);
+    init_acc(0);
+    store_tile();
+    for (int stage = 0; stage < n_stages; ++stage) {
+        const int k = stage / n_chunks, chunk = stage - k * n_chunks;
+        const int grp = (int)((blockIdx.x + k * gridDim.x) % a.groups);
+        if (chunk == 0) {
+            finish_acc();
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                float bv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bv[r] = a.bias[grp * COUTP + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl];   // padded
+#pragma unroll
+                for (int q = 0; q < RPW; ++q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[q][m][r] += bv[r];
+            }
+        }
+        __syncthreads();                                   // this stage's tile is visible
+        const bool next_stage = (stage + 1 < n_stages);
+        const int next_chunk = (chunk + 1 == n_chunks) ? 0 : chunk + 1;
+        const int next_grp = (next_chunk == 0) ? (int)((blockIdx.x + (k + 1) * gridDim.x) % a.groups) : grp;
+        // B fragments of tap t: [q][piece]; read one tap ahead of the MFMAs that consume them
+        uint4 bc[RPW][3], bn[RPW][3];
+        auto read_b = [&](int tap, uint4 (&b)[RPW][3]) {
+            const int ky = tap / KW, kx = tap - ky * KW;
+            const uint4 *bp = tin + ((wave * RPW + ky) * 2 + hl) * TWP + (COL0 - PADX) + kx + nl;
+#pragma unroll
+            for (int q = 0; q < RPW; ++q)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[q][p] = bp[p * PSZ + q * 2 * TWP];
+        };
+        auto mfma6 = [&](const uint4 (&w)[3][MT], const uint4 (&b)[RPW][3]) {
+            bf16x8 bf[RPW][3];
+#pragma unroll
+            for (int q = 0; q < RPW; ++q)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bf[q][p] = __builtin_bit_cast(bf16x8, b[q][p]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, w[0][m]), am = __builtin_bit_cast(bf16x8, w[1][m]),
+                             al = __builtin_bit_cast(bf16x8, w[2][m]);
+#pragma unroll
+                for (int q = 0; q < RPW; ++q) {            // small terms first
+                    acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bf[q][0], acc[q][m], 0, 0, 0);
+                    acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bf[q][2], acc[q][m], 0, 0, 0);
+                    acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bf[q][1], acc[q][m], 0, 0, 0);
+                    acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bf[q][0], acc[q][m], 0, 0, 0);
+                    acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bf[q][1], acc[q][m], 0, 0, 0);
+                    acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bf[q][0], acc[q][m], 0, 0, 0);
+                }
+            }
+        };
+        read_b(0, bc);
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const bool last_tap = (tap + 1 == TAPS);
+            if (!last_tap) read_b(tap + 1, bn);
+            if ((tap & 1) == 0) {
+                if (!last_tap) load_w(grp, chunk, tap + 1, wb);
+                else if (next_stage) load_w(next_grp, next_chunk, 0, wb);
+                if (tap == 0 && next_stage) fetch_tile(stage + 1);   // next halo tile: in flight under this stage's MFMAs
+                mfma6(wa, bc);
+            } else {
+                if (!last_tap) load_w(grp, chunk, tap + 1, wa);
+                else if (next_stage) load_w(next_grp, next_chunk, 0, wa);
+                mfma6(wb, bc);
+            }
+#pragma unroll
+            for (int q = 0; q < RPW; ++q)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bc[q][p] = bn[q][p];
+        }
+        if ((TAPS & 1) == 1) {   // odd tap count: the next stage's tap-0 weights sit in wb
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) wa[p][m] = wb[p][m];
+        }
+        if (chunk + 1 == n_chunks) {
+            // ---- epilogue: lane owns pixels (y0 + wave*RPW + q, x0+nl), channels (r&3)+8(r>>2)+4hl of each 32-tile ----
+            const int t = (blockIdx.x + k * gridDim.x) / a.groups;
+            const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
+            float *__restrict__ out = a.out + (size_t)n * a.out_bstride + (size_t)grp * COUTP * plane;
+            const float *__restrict__ res = a.residual ? a.residual + (size_t)n * a.res_bstride + (size_t)grp * COUTP * plane : nullptr;
+            const bool late_res = (res != nullptr) && !res_in_acc;
+            const int cout_g = a.cout - grp * COUTP;
+            const bool full = (cout_g >= COUTP);
+            const int x4 = tx * kSpTW + 4 * (lane & 7);
+#pragma unroll
+            for (int q = 0; q < RPW; ++q) {
+                const int y = ty * kSpTH + wave * RPW + q;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[q][m][r];
+                        if (a.act) v = split_act<GEN>(v, a.act);
+                        if (a.clamp && !late_res) v = fminf(fmaxf(v, 0.f), 1.f);
+                        stg[((r & 3) + 8 * (r >> 2) + 4 * hl) * 32 + nl] = v;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int co = m * 32 + (lane >> 3) + 8 * j;
+                        float4 v = *reinterpret_cast<const float4 *>(stg + ((lane >> 3) + 8 * j) * 32 + 4 * (lane & 7));
+                        if (y < a.H && x4 < a.W && (full || co < cout_g)) {
+                            const unsigned int o = (unsigned int)co * uplane + (unsigned int)(y * a.W + x4);
+                            if (late_res) {
+                                const float4 rr = *reinterpret_cast<const float4 *>(res + o);
+                                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                                if (a.clamp) {
+                                    v.x = fminf(fmaxf(v.x, 0.f), 1.f); v.y = fminf(fmaxf(v.y, 0.f), 1.f);
+                                    v.z = fminf(fmaxf(v.z, 0.f), 1.f); v.w = fminf(fmaxf(v.w, 0.f), 1.f);
+                                }
+                            }
+                            *reinterpret_cast<float4 *>(out + o) = v;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            if (next_stage) init_acc(k + 1);
+        }
+        __syncthreads();                   // every wave is done reading this stage's tile
+        if (next_stage) store_tile();
+    }
+}
+
+template <int KH, int KW, bool GEN>
+static int launch_split(const ConvArgs &a, int N, hipStream_t s) {
+    constexpr int ROWS = kSpTH + KH - 1, TWP = (KW > 1) ? kSpTW + 8 : kSpTW;
+    const size_t lds = (size_t)3 * ROWS * 2 * TWP * 16 + (size_t)4 * 32 * 32 * sizeof(float);
+    const int tiles_x = (a.W + kSpTW - 1) / kSpTW, tiles_y = (a.H + kSpTH - 1) / kSpTH;
+    const long long n_tiles = (long long)tiles_x * tiles_y * N * a.groups;
+    if (n_tiles > 0x7fffffffLL) return CT_E_BADARG;
+    const int grid = n_tiles < 2 * kSpCUs ? (int)n_tiles : 2 * kSpCUs;
+    hipLaunchKernelGGL((conv_split_kernel<KH, KW, GEN>), dim3(grid), dim3(256), lds, s, a, tiles_x, tiles_y, (int)n_tiles);
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+}
+
+// 1 = this geometry / alignment has no split-bf16 kernel (the caller uses the exact-f32 one)
+int conv_split(const ConvArgs &a, int N, int kh, int kw, bool gen, hipStream_t s) {
+    const bool vec = (a.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.in) & 15) == 0) && (a.in_bstride % 4 == 0) &&
+                     ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0) && (a.out_bstride % 4 == 0) &&
+                     ((reinterpret_cast<uintptr_t>(a.wp) & 15) == 0) &&
+                     (!a.residual || (((reinterpret_cast<uintptr_t>(a.residual) & 15) == 0) && (a.res_bstride % 4 == 0)));
+    if (!vec) return 1;
+    if (gen) {
+        if (kh == 3 && kw == 3) return launch_split<3, 3, true>(a, N, s);
+        if (kh == 1 && kw == 1) return launch_split<1, 1, true>(a, N, s);
+        if (kh == 1 && kw == 5) return launch_split<1, 5, true>(a, N, s);
+        if (kh == 5 && kw == 1) return launch_split<5, 1, true>(a, N, s);
+    } else {
+        if (kh == 3 && kw == 3) return launch_split<3, 3, false>(a, N, s);
+        if (kh == 1 && kw == 1) return launch_split<1, 1, false>(a, N, s);
+    }
+    return 1;
+}
+
+}  // namespace ct
+
+extern "C" {
+
+int ct_conv2d_split_f32(const float *in, const void *wp_split, const float *bias, const float *residual, float *out, int n, int cin,
+                        int cout, int h, int w, int kh, int kw, long long in_bstride, long long out_bstride,
+                        long long res_bstride, int act, int clamp, void *stream) {
+    if (!in || !wp_split || !bias || !out || n < 0 || cin < 1 || cout < 1 || h < 0 || w < 0 || act < 0 || act > 4) return CT_E_BADARG;
+    if (n == 0 || h == 0 || w == 0) return CT_OK;
+    ct::ConvArgs a;
+    a.in = in; a.wp = reinterpret_cast<const float *>(wp_split); a.bias = bias; a.residual = residual; a.out = out;
+    a.cin = cin; a.cout = cout; a.H = h; a.W = w;
+    a.in_bstride = in_bstride; a.out_bstride = out_bstride; a.res_bstride = res_bstride;
+    a.act = act; a.clamp = clamp; a.groups = (cout + 63) / 64; a.prof = nullptr;
+    const int rc = ct::conv_split(a, n, kh, kw, true, (hipStream_t)stream);
+    return rc == 1 ? CT_E_BADARG : rc;
+}
+
+}  // extern "C"

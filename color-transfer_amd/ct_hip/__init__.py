@@ -324,9 +324,71 @@ SIGNATURES.update({
     "ct_conv2d_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ll, _c_ll,
                                _c_ll, _c_int, _c_int, _c_p]),
     "ct_pam_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
+    "ct_conv2d_split_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ll,
+                                     _c_ll, _c_ll, _c_int, _c_int, _c_p]),
     "ct_pam_attend_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "ct_pam_valid_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_sz, _c_p]),
 })
+
+
+# ---- convolution arithmetic --------------------------------------------------------------------------------------
+# "split": float32 operands as three bf16 pieces, six bf16 MFMAs per product (csrc/conv_split.hip; float32-grade
+#          accuracy, 2.67x the matrix rate).  "exact": v_mfma_f32_32x32x2_f32, bitwise an fmaf chain (csrc/cnn.hip).
+# Geometries the split kernel does not cover (stride 2, 7x7, W % 4 != 0, unaligned views) always run "exact".
+_conv_mode = os.environ.get("CT_HIP_CONV", "split")
+
+
+def set_conv_mode(mode):
+    global _conv_mode
+    if mode not in ("split", "exact"):
+        raise ValueError("conv mode must be 'split' or 'exact'")
+    _conv_mode = mode
+
+
+def conv_mode():
+    return _conv_mode
+
+
+def pack_conv_weight_split(weight, bias):
+    """Conv2d parameters -> ct_conv2d_split_f32 operands: bf16 bit patterns (int16)
+    [ceil(cout/64)][ceil(cin/16)][kh*kw][piece hi/mid/lo][m 0..1][k-half 0..1][cout%32][8 channels], and the bias
+    zero-padded to 64*ceil(cout/64)."""
+    cout, cin, kh, kw = weight.shape
+    g, nc = (cout + 63) // 64, (cin + 15) // 16
+    w = torch.zeros((g * 64, nc * 16, kh, kw), dtype=torch.float32, device=weight.device)
+    w[:cout, :cin] = weight.detach().float()
+    hi = w.to(torch.bfloat16)
+    r1 = w - hi.float()
+    r1 = torch.where(torch.isfinite(r1), r1, torch.zeros_like(r1))
+    mid = r1.to(torch.bfloat16)
+    lo = (r1 - mid.float()).to(torch.bfloat16)
+    pieces = torch.stack([hi, mid, lo], dim=0).view(torch.int16)           # [3][coutp][cinp][kh][kw]
+    pieces = pieces.reshape(3, g, 2, 32, nc, 2, 8, kh * kw)                # piece, g, m, r, chunk, h, j, tap
+    ws = pieces.permute(1, 4, 7, 0, 2, 5, 3, 6).contiguous()               # g, chunk, tap, piece, m, h, r, j
+    b = torch.zeros(g * 64, dtype=torch.float32, device=weight.device)
+    if bias is not None:
+        b[:cout] = bias.detach().float()
+    return ws, b
+
+
+def _split_ok(x, out, residual, kh, kw, stride, ph, pw):
+    if _conv_mode != "split" or stride != 1 or (kh, kw) not in ((3, 3), (1, 1), (1, 5), (5, 1)) or (ph, pw) != (kh // 2, kw // 2):
+        return False
+    if x.shape[3] % 4:
+        return False
+    for t in (x, out, residual):
+        if t is not None and (t.data_ptr() % 16 or t.stride(0) % 4):
+            return False
+    return True
+
+
+def _conv_split(x, split, cout, kh, kw, act, residual, clamp, out):
+    ws, b64 = split
+    n, cin, h, w = x.shape
+    rs = _nchw_bstride(residual) if residual is not None else 0
+    check(lib().ct_conv2d_split_f32(_ptr(x), _ptr(ws), _ptr(b64), _opt(residual), _ptr(out), n, cin, cout, h, w, kh, kw,
+                                    _nchw_bstride(x), _nchw_bstride(out), rs, int(act), int(bool(clamp)), _stream()))
+    return out
 
 
 def pack_conv_weight(weight, bias):
@@ -342,6 +404,7 @@ def pack_conv_weight(weight, bias):
     b = torch.zeros(coutp, dtype=torch.float32, device=weight.device)
     if bias is not None:
         b[:cout] = bias.detach().float()
+    wp._ct_split = pack_conv_weight_split(weight, bias)      # operands of the split-bf16 kernel travel with the packing
     return wp, b
 
 
@@ -359,6 +422,9 @@ def conv2d(x, wp, bias, cout, ksize, act=0, residual=None, clamp=False, out=None
     n, cin, h, w = x.shape
     if out is None:
         out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+    split = getattr(wp, "_ct_split", None)
+    if split is not None and _split_ok(x, out, residual, ksize, ksize, 1, ksize // 2, ksize // 2):
+        return _conv_split(x, split, cout, ksize, ksize, act, residual, clamp, out)
     rs = _nchw_bstride(residual) if residual is not None else 0
     check(lib().ct_conv2d_f32(_ptr(x), _ptr(wp), _ptr(bias), _ptr(residual) if residual is not None else _c_p(0),
                               _ptr(out), n, cin, cout, h, w, ksize, _nchw_bstride(x), _nchw_bstride(out), rs, int(act),
@@ -450,6 +516,8 @@ def pack_gconv_weight(weight, bias):
     b = torch.zeros(coutp, dtype=torch.float32, device=weight.device)
     if bias is not None:
         b[:cout] = bias.detach().float()
+    if kh * kw <= 9:
+        wp._ct_split = pack_conv_weight_split(weight, bias)
     return wp, b
 
 
@@ -460,6 +528,9 @@ def gconv2d(x, wp, bias, cout, ksize, stride=1, padding=0, act=ACT_NONE, out=Non
     ho, wo = (h + 2 * ph - kh) // stride + 1, (w + 2 * pw - kw) // stride + 1
     if out is None:
         out = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device)
+    split = getattr(wp, "_ct_split", None)
+    if split is not None and bias is not None and _split_ok(x, out, None, kh, kw, stride, ph, pw):
+        return _conv_split(x, split, cout, kh, kw, act, None, False, out)
     check(lib().ct_gconv2d_f32(_ptr(x), _ptr(wp), _opt(bias), _ptr(out), n, cin, cout, h, w, kh, kw, stride, ph, pw,
                                _nchw_bstride(x), _nchw_bstride(out), int(act), _stream()))
     return out

@@ -48,6 +48,38 @@ def test_gconv(hip, cfg):
     close(hip.gconv2d(x.cuda(), wp, None, cout, (kh, kw), s, (ph, pw)), ref - b.double().view(1, -1, 1, 1), "no bias")
 
 
+@pytest.mark.parametrize("cfg", [
+    (2, 64, 64, 24, 64, 3, 3), (1, 3, 64, 16, 32, 3, 3), (1, 64, 32, 9, 36, 3, 3), (1, 32, 3, 16, 40, 3, 3),
+    (1, 129, 64, 8, 32, 1, 1), (2, 384, 128, 20, 68, 1, 5), (2, 384, 128, 21, 68, 5, 1), (1, 130, 256, 24, 64, 3, 3),
+    (1, 81, 256, 8, 32, 1, 1)])
+def test_conv_split_bf16(hip, cfg):
+    """three-way bf16 split of both operands, six MFMAs per product: float32-grade accuracy (csrc/conv_split.hip)"""
+    n, cin, cout, h, w, kh, kw = cfg
+    x, wt, b = rnd(n, cin, h, w) * 3, rnd(cout, cin, kh, kw) / (cin * kh * kw) ** 0.5, rnd(cout)
+    res = rnd(n, cout, h, w)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=(kh // 2, kw // 2))
+    ws, b64 = hip.pack_conv_weight_split(wt.cuda(), b.cuda())
+    out = torch.empty(n, cout, h, w, device="cuda")
+    tol = 2e-6 * max(1.0, ref.abs().max().item())          # float32 accumulation of ~cin*kh*kw terms of this magnitude
+    for act, fn in ((0, lambda t: t), (1, lambda t: F.leaky_relu(t, 0.01)), (2, torch.relu), (3, torch.sigmoid), (4, torch.tanh)):
+        hip._conv_split(x.cuda(), (ws, b64), cout, kh, kw, act, None, False, out)
+        err = (out.double().cpu() - fn(ref)).abs().max().item()
+        assert err < tol, ("split conv", cfg, act, err)
+    hip._conv_split(x.cuda(), (ws, b64), cout, kh, kw, 0, res.cuda(), True, out)          # ResB skip in the accumulators + clamp
+    close(out, (ref + res.double()).clamp(0, 1), "split conv + skip + clamp", atol=tol, rtol=0)
+    hip._conv_split(x.cuda(), (ws, b64), cout, kh, kw, 2, res.cuda(), False, out)         # activation then skip
+    close(out, torch.relu(ref) + res.double(), "split conv, relu, + skip", atol=tol, rtol=0)
+    # the exact-f32 kernel on the same operands: the two agree to float32 rounding level
+    wp, bp = hip.pack_gconv_weight(wt.cuda(), b.cuda())
+    hip.set_conv_mode("exact")
+    try:
+        exact = hip.gconv2d(x.cuda(), wp, bp, cout, (kh, kw), 1, (kh // 2, kw // 2))
+    finally:
+        hip.set_conv_mode("split")
+    hip._conv_split(x.cuda(), (ws, b64), cout, kh, kw, 0, None, False, out)
+    assert (out - exact).abs().max().item() < 2 * tol
+
+
 def test_instance_norm(hip):
     x, skip = rnd(2, 5, 17, 23) * 3 + 1, rnd(2, 5, 17, 23)
     ref = F.instance_norm(x.double(), eps=1e-5)
