@@ -8,8 +8,8 @@
 // v_mfma_f32_32x32x16_bf16 (32 cycles each, K = 16) replace eight 32x32x2 f32 MFMAs (64 cycles each): 2.67x the
 // throughput at the same accuracy class (NOT bitwise the fmaf chain of the f32 kernel; parity bars are unchanged).
 //
-// Same implicit GEMM as conv_mfma_kernel: M = 64 output channels (A = weights, pre-split on the host, streamed from
-// L1/L2 into registers), N = 32 consecutive pixels of a row (B from an LDS halo tile), persistent workgroups walking
+// Same implicit GEMM as conv_mfma_kernel: M = 64 output channels (A = weights, pre-split on the host, streamed by one wave
+// from L2 through a two-tap LDS ring), N = 32 consecutive pixels of a row (B from an LDS halo tile), persistent workgroups walking
 // 8x32-pixel tiles, 16 input channels per stage (= one bf16 K step per tap).  The float32 NCHW input is split while it
 // is staged: a thread fetches 8 channels x 4 pixels with 16-byte loads, converts in registers and writes the LDS tile
 // [piece][row][k-half][column][8 channels] so that an MFMA B fragment (8 consecutive channels of one pixel) is one
@@ -40,17 +40,39 @@ __device__ __forceinline__ float split_act(float v, int act) {
     }
 }
 
-// x -> (hi, mid, lo) bf16 bit patterns; hi + mid + lo == x up to 2^-24 relative.  Infinities keep mid = lo = 0.
+// x -> (hi, mid, lo) bf16 bit patterns; hi + mid + lo == x up to 2^-24 relative.  NaN stays NaN; an infinity becomes
+// (inf, NaN, NaN), i.e. an infinite activation yields NaN outputs where the f32 kernel yields +-inf / NaN.
 __device__ __forceinline__ void split3(float x, unsigned int &h, unsigned int &m, unsigned int &l) {
     const __bf16 bh = (__bf16)x;
-    float r1 = x - (float)bh;
-    r1 = (r1 == r1) ? r1 : 0.f;
+    const float r1 = x - (float)bh;
     const __bf16 bm = (__bf16)r1;
     const float r2 = r1 - (float)bm;
     const __bf16 bl = (__bf16)r2;
     h = __builtin_bit_cast(unsigned short, bh);
     m = __builtin_bit_cast(unsigned short, bm);
     l = __builtin_bit_cast(unsigned short, bl);
+}
+
+// two values at once, packed (x0 in the low half): one v_cvt_pk_bf16_f32 per piece, halves re-expanded by shift / mask
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int pack_bf16(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ void split3x2(float x0, float x1, unsigned int &hw, unsigned int &mw, unsigned int &lw) {
+    hw = pack_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(hw << 16), r1 = x1 - __uint_as_float(hw & 0xffff0000u);
+    mw = pack_bf16(r0, r1);
+    lw = pack_bf16(r0 - __uint_as_float(mw << 16), r1 - __uint_as_float(mw & 0xffff0000u));
+}
+
+// LDS-DMA: 64 lanes x 16 bytes from global straight into LDS at lds_addr + 16 * lane (no registers).  Issued through
+// inline asm on purpose: behind the builtin the compiler puts an s_waitcnt vmcnt(0) in front of every later LDS read
+// (it cannot tell which ones alias), i.e. the streaming wave would wait out the full L2 latency of the loads it has
+// just issued; here the landing is awaited explicitly, with a counted vmcnt, right before the publishing barrier.
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned int lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_addr) : "memory");   // m0 is not used by anything else in this kernel (checked in the ISA)
 }
 
 // wp : bf16 bit patterns [group][chunk16][tap][piece][m][lane = 32*khalf + cout%32][8 channels]   (host: pack_conv_weight_split)
@@ -65,12 +87,16 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
     constexpr int NU = 2 * ROWS * 8;                   // (k-half, row, 4-column group) units of 8 channels x 4 pixels
     constexpr int HC = KW - 1;
     constexpr int NE = kSpKC * ROWS * HC;              // halo scalars per stage
-    constexpr int PFE = (NE + 255) / 256;
+    constexpr int NF = 192;                            // threads that fetch the input tile (waves 0..2; wave 3 streams weights)
+    constexpr int PFE = (NE + NF - 1) / NF;
     constexpr int MT = 2, COUTP = 64, RPW = kSpTH / 4, TAPS = KH * KW;
-    static_assert(NU <= 256, "tile geometry");
+    static_assert(NU <= NF, "tile geometry");
     extern __shared__ uint4 smem16[];
+    constexpr int WSLOT = 3 * MT * 64;                  // 16-byte entries of one tap's weight fragments
     uint4 *tin = smem16;                                // [3][ROWS][2][TWP]
-    float *stg = reinterpret_cast<float *>(smem16 + 3 * PSZ) + (threadIdx.x >> 6) * (32 * 32);
+    constexpr int WRING = 4;                            // taps of weights resident in LDS
+    uint4 *wl = smem16 + 3 * PSZ;                       // [WRING][piece][m][lane]
+    float *stg = reinterpret_cast<float *>(smem16 + 3 * PSZ + WRING * WSLOT) + (threadIdx.x >> 6) * (32 * 32);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, hl = lane >> 5;
     const size_t plane = (size_t)a.H * a.W;
@@ -106,12 +132,12 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
         if (HALO) {
 #pragma unroll
             for (int j = 0; j < PFE; ++j) {
-                const int e = (255 - tid) + j * 256;              // the threads without a unit take the halo first
+                const int e = (NF - 1 - tid) + j * NF;            // the fetch threads without a unit take the halo first
                 const int c = e / (ROWS * HC), rem = e - c * (ROWS * HC);
                 const int yy = rem / HC, side = rem - yy * HC;
                 const int gy = y0 + yy - PADY, gx = side < PADX ? x0 - PADX + side : x0 + kSpTW + side - PADX;
                 float v = 0.f;
-                if (e < NE && c0 + c < a.cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                if (tid < NF && e < NE && c0 + c < a.cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
                     v = in[(unsigned int)c * uplane + (unsigned int)(gy * a.W + gx)];
                 pfe[j] = v;
             }
@@ -128,10 +154,14 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
                     const float4 v0 = pf4[2 * jp], v1 = pf4[2 * jp + 1];
                     const float x0 = px == 0 ? v0.x : px == 1 ? v0.y : px == 2 ? v0.z : v0.w;
                     const float x1 = px == 0 ? v1.x : px == 1 ? v1.y : px == 2 ? v1.z : v1.w;
+#ifdef CT_SPLIT_SCALAR
                     unsigned int h0, m0, l0, h1, m1, l1;
                     split3(x0, h0, m0, l0);
                     split3(x1, h1, m1, l1);
                     hw[jp] = h0 | (h1 << 16); mw[jp] = m0 | (m1 << 16); lw[jp] = l0 | (l1 << 16);
+#else
+                    split3x2(x0, x1, hw[jp], mw[jp], lw[jp]);
+#endif
                 }
                 dst[px] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
                 dst[PSZ + px] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
@@ -142,11 +172,11 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
             unsigned short *t16 = reinterpret_cast<unsigned short *>(tin);
 #pragma unroll
             for (int j = 0; j < PFE; ++j) {
-                const int e = (255 - tid) + j * 256;
+                const int e = (NF - 1 - tid) + j * NF;
                 const int c = e / (ROWS * HC), rem = e - c * (ROWS * HC);
                 const int yy = rem / HC, side = rem - yy * HC;
                 const int col = side < PADX ? COL0 - PADX + side : COL0 + kSpTW + side - PADX;
-                if (e < NE) {
+                if (tid < NF && e < NE) {
                     unsigned int h, m, l;
                     split3(pfe[j], h, m, l);
                     const int idx = ((yy * 2 + (c >> 3)) * TWP + col) * 8 + (c & 7);
@@ -157,18 +187,52 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
             }
         }
     };
-    // ---- A operand: weights of one (tap, chunk): [piece][m] 16-byte fragments, coalesced 1 KiB per (piece, m) ----
+    // ---- A operand: wave 3 streams the weight fragments of one tap ([piece][m], 1 KiB each) from L2 straight into a
+    // four-slot LDS ring with LDS-DMA loads (global_load_lds_dwordx4: no registers), three taps ahead of their use;
+    // every wave reads its fragments from there.  (Per-wave register loads would tie the weights to the input-tile
+    // fetch through the in-order vmcnt counter: each weight wait would also wait for the HBM latency of the tile loads
+    // issued before it; and an L2 round trip is several taps long.)  g = stage * TAPS + tap counts this workgroup's taps.
     const uint4 *wp16 = reinterpret_cast<const uint4 *>(a.wp);
-    auto load_w = [&](int grp, int chunk, int tap, uint4 (&w)[3][MT]) {
-        const uint4 *src = wp16 + ((((size_t)grp * n_chunks + chunk) * TAPS + tap) * 3 * MT) * 64 + lane;
+    const bool wloader = (wave == 3);
+    const unsigned int wl_addr = (unsigned int)reinterpret_cast<uintptr_t>(wl);   // LDS byte address (low half of the flat address)
+    const int n_gtaps = n_stages * TAPS;
+    // issue cursor (taps are issued strictly in order, so no divisions): tap within the stage, chunk, group, ring slot
+    int wi_tap = 0, wi_chunk = 0, wi_k = 0, wi_grp = (int)(blockIdx.x % a.groups), wi_slot = 0;
+    auto w_issue = [&](int /*g*/) {
+        const uint4 *src = wp16 + ((((size_t)wi_grp * n_chunks + wi_chunk) * TAPS + wi_tap) * 3 * MT) * 64 + lane;
+        const unsigned int dst = wl_addr + (unsigned int)(wi_slot * WSLOT * 16);   // + 16 * lane is implied by the instruction
+        if (wloader) {                                     // the cursor below advances in every wave: it stays scalar
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) w[p][m] = src[(p * MT + m) * 64];
+            for (int f = 0; f < 3 * MT; ++f) glds16(src + f * 64, __builtin_amdgcn_readfirstlane(dst + f * 1024));
+        }
+        wi_slot = (wi_slot + 1 == WRING) ? 0 : wi_slot + 1;
+        if (++wi_tap == TAPS) {
+            wi_tap = 0;
+            if (++wi_chunk == n_chunks) {
+                wi_chunk = 0;
+                ++wi_k;
+                wi_grp = (int)((blockIdx.x + wi_k * gridDim.x) % a.groups);
+            }
+        }
+    };
+    // before the barrier that ends tap g: the fragments of tap g+1 have landed (loads of later taps may be in flight)
+    auto w_landed = [&](int g) {
+        const int ahead = n_gtaps - g - 2;                 // taps issued after tap g+1
+        if (ahead >= 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * 3 * MT));      // vmcnt(12)
+        else if (ahead == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (3 * MT));     // vmcnt(6)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                                 // vmcnt(0)
     };
 
+#ifdef CT_CONV_PROFILE
+    // diagnostic build (make prof, tools/prof_conv_split.py): per-phase cycle totals of every wave 0 -> a.prof[block][8]
+    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt0;
+#define CT_STAMP(var) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#define CT_PHASE(i) do { unsigned long long t__; CT_STAMP(t__); pt[i] += t__ - pt0; pt0 = t__; } while (0)
+    CT_STAMP(pt0);
+#else
+#define CT_PHASE(i) do { } while (0)
+#endif
     f32x16s acc[RPW][MT];
-    uint4 wa[3][MT], wb[3][MT];
     // phase stagger of the two co-resident workgroups (see conv_mfma_kernel)
     if (my_tiles >= 2) {
         const unsigned int hw_wave_slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | ((4 - 1) << 11));   // HW_ID[3:0]
@@ -218,7 +282,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
             }
     };
 
-    load_w((int)blockIdx.x % a.groups, 0, 0, wa);
+    w_issue(0);
+    if (n_gtaps > 1) w_issue(1);
+    if (n_gtaps > 2) w_issue(2);
+    if (wloader) w_landed(-1);
     fetch_tile(0);
     init_acc(0);
     store_tile();
@@ -238,10 +305,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
                     for (int r = 0; r < 16; ++r) acc[q][m][r] += bv[r];
             }
         }
+        CT_PHASE(0);                                       // store_tile / accumulator init
         __syncthreads();                                   // this stage's tile is visible
+        CT_PHASE(1);
         const bool next_stage = (stage + 1 < n_stages);
-        const int next_chunk = (chunk + 1 == n_chunks) ? 0 : chunk + 1;
-        const int next_grp = (next_chunk == 0) ? (int)((blockIdx.x + (k + 1) * gridDim.x) % a.groups) : grp;
         // B fragments of tap t: [q][piece]; read one tap ahead of the MFMAs that consume them
         uint4 bc[RPW][3], bn[RPW][3];
         auto read_b = [&](int tap, uint4 (&b)[RPW][3]) {
@@ -252,7 +319,12 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
 #pragma unroll
                 for (int p = 0; p < 3; ++p) b[q][p] = bp[p * PSZ + q * 2 * TWP];
         };
-        auto mfma6 = [&](const uint4 (&w)[3][MT], const uint4 (&b)[RPW][3]) {
+        auto mfma6 = [&](const uint4 *ws, const uint4 (&b)[RPW][3]) {
+            uint4 w[3][MT];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) w[p][m] = ws[(p * MT + m) * 64];
             bf16x8 bf[RPW][3];
 #pragma unroll
             for (int q = 0; q < RPW; ++q)
@@ -277,27 +349,19 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const bool last_tap = (tap + 1 == TAPS);
+            const int g = stage * TAPS + tap;
+            if (g + 3 < n_gtaps) w_issue(g + 3);   // slot (g+3)%4 was last read in tap g-1: free since that barrier
+            if (tap == 0 && next_stage) fetch_tile(stage + 1);   // next halo tile: in flight under this stage's MFMAs
             if (!last_tap) read_b(tap + 1, bn);
-            if ((tap & 1) == 0) {
-                if (!last_tap) load_w(grp, chunk, tap + 1, wb);
-                else if (next_stage) load_w(next_grp, next_chunk, 0, wb);
-                if (tap == 0 && next_stage) fetch_tile(stage + 1);   // next halo tile: in flight under this stage's MFMAs
-                mfma6(wa, bc);
-            } else {
-                if (!last_tap) load_w(grp, chunk, tap + 1, wa);
-                else if (next_stage) load_w(next_grp, next_chunk, 0, wa);
-                mfma6(wb, bc);
-            }
+            mfma6(wl + (g % WRING) * WSLOT + lane, bc);
 #pragma unroll
             for (int q = 0; q < RPW; ++q)
 #pragma unroll
                 for (int p = 0; p < 3; ++p) bc[q][p] = bn[q][p];
-        }
-        if ((TAPS & 1) == 1) {   // odd tap count: the next stage's tap-0 weights sit in wb
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-#pragma unroll
-                for (int m = 0; m < MT; ++m) wa[p][m] = wb[p][m];
+            CT_PHASE(2);                                     // tap work: LDS operand reads + MFMAs (+ prefetch issue)
+            if (wloader) { w_landed(g); CT_PHASE(6); }
+            if (!last_tap) __syncthreads();                  // weight slot g%4 is free, slot (g+1)%4 is published
+            CT_PHASE(5);
         }
         if (chunk + 1 == n_chunks) {
             // ---- epilogue: lane owns pixels (y0 + wave*RPW + q, x0+nl), channels (r&3)+8(r>>2)+4hl of each 32-tile ----
@@ -344,19 +408,29 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
             }
             if (next_stage) init_acc(k + 1);
         }
+        CT_PHASE(3);                       // epilogue
         __syncthreads();                   // every wave is done reading this stage's tile
+        CT_PHASE(4);
         if (next_stage) store_tile();
     }
+#ifdef CT_CONV_PROFILE
+    CT_PHASE(0);
+    if (lane == 0 && (wave == 0 || wave == 3) && a.prof) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a.prof[((size_t)(wave ? 512 : 0) + blockIdx.x) * 8 + i] = pt[i];
+    }
+#endif
 }
 
 template <int KH, int KW, bool GEN>
 static int launch_split(const ConvArgs &a, int N, hipStream_t s) {
     constexpr int ROWS = kSpTH + KH - 1, TWP = (KW > 1) ? kSpTW + 8 : kSpTW;
-    const size_t lds = (size_t)3 * ROWS * 2 * TWP * 16 + (size_t)4 * 32 * 32 * sizeof(float);
+    const size_t lds = (size_t)3 * ROWS * 2 * TWP * 16 + (size_t)4 * 3 * 2 * 64 * 16 + (size_t)4 * 32 * 32 * sizeof(float);
     const int tiles_x = (a.W + kSpTW - 1) / kSpTW, tiles_y = (a.H + kSpTH - 1) / kSpTH;
     const long long n_tiles = (long long)tiles_x * tiles_y * N * a.groups;
     if (n_tiles > 0x7fffffffLL) return CT_E_BADARG;
-    const int grid = n_tiles < 2 * kSpCUs ? (int)n_tiles : 2 * kSpCUs;
+    static const int wgs_per_cu = [] { const char *e = getenv("CT_HIP_SPLIT_WGS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 2; }();
+    const int grid = n_tiles < wgs_per_cu * kSpCUs ? (int)n_tiles : wgs_per_cu * kSpCUs;
     hipLaunchKernelGGL((conv_split_kernel<KH, KW, GEN>), dim3(grid), dim3(256), lds, s, a, tiles_x, tiles_y, (int)n_tiles);
     CT_CHECK_LAUNCH();
     return CT_OK;
@@ -398,5 +472,17 @@ int ct_conv2d_split_f32(const float *in, const void *wp_split, const float *bias
     const int rc = ct::conv_split(a, n, kh, kw, true, (hipStream_t)stream);
     return rc == 1 ? CT_E_BADARG : rc;
 }
+
+#ifdef CT_CONV_PROFILE
+int ct_conv2d_split_prof_f32(const float *in, const void *wp_split, const float *bias, const float *residual, float *out, int n,
+                             int cin, int cout, int h, int w, unsigned long long *prof, void *stream) {
+    ct::ConvArgs a;
+    a.in = in; a.wp = reinterpret_cast<const float *>(wp_split); a.bias = bias; a.residual = residual; a.out = out;
+    a.cin = cin; a.cout = cout; a.H = h; a.W = w;
+    a.in_bstride = (long long)cin * h * w; a.out_bstride = (long long)cout * h * w; a.res_bstride = a.out_bstride;
+    a.act = 0; a.clamp = 0; a.groups = (cout + 63) / 64; a.prof = prof;
+    return ct::conv_split(a, n, 3, 3, false, (hipStream_t)stream);
+}
+#endif
 
 }  // extern "C"
