@@ -194,7 +194,10 @@ def main():
             extra["idt_pairs_per_s_f64"] = idt                           # B pairs per call, like the headline
             extra["idt_frac_hbm_peak"] = 920678400 * idt / HBM_PEAK      # float64 working image
             del idt_out
-            # configs[2]: DCMCS3DI forward, random init, 512x512, exact-f32 MFMA (peak 157.3 TFLOP/s)
+            # configs[2]: DCMCS3DI forward, random init, 512x512.  The convolutions run float32 operands as three bf16
+            # pieces with six bf16 MFMAs per product (float32-grade accuracy, csrc/conv_split.hip); rates are quoted in
+            # algorithmic (float32) FLOPs against the FP32 matrix peak, and x6 against the dense bf16 peak.
+            extra["cnn_conv_arithmetic"] = "f32 as 3 bf16 pieces, 6 bf16 MFMAs per product, f32 accumulate (%s mode)" % ct_hip.conv_mode()
             from methods.dcmcs3di import DCMCS3DI
             torch.manual_seed(0)
             net = DCMCS3DI().to(device).eval()
@@ -204,6 +207,7 @@ def main():
             extra["dcmcs3di_512_pairs_per_s_f32"] = dc
             extra["dcmcs3di_512_tflops"] = flop * dc / 1e12
             extra["dcmcs3di_512_frac_fp32_mfma_peak"] = flop * dc / 157.3e12
+            extra["dcmcs3di_512_frac_bf16_mfma_peak_x6"] = 6 * flop * dc / 2.5e15   # six bf16 MFMA flops per algorithmic flop
             # the size BASELINE.json's metric names: 1920x1080 (H*W*(6591040 + 390*W) FLOP/pair)
             l1080, r1080 = torch.rand(1, 3, H, W, device=device), torch.rand(1, 3, H, W, device=device)
             dc2 = rate(lambda: net(l1080, r1080, inference=True), n=2)

@@ -43,3 +43,12 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(params=["split", "exact"])
+def conv_mode(request):
+    """Both arithmetic paths of the stride-1 convolutions: split-bf16 MFMA (default) and exact-f32 MFMA."""
+    import ct_hip
+    ct_hip.set_conv_mode(request.param)
+    yield request.param
+    ct_hip.set_conv_mode("split")

@@ -1,4 +1,4 @@
-"""GPU parity for the DCMCS3DI forward (exact-f32 MFMA convs + fused parallax attention) against
+"""GPU parity for the DCMCS3DI forward (split-bf16 and exact-f32 MFMA convs + fused parallax attention) against
 goldens captured from the real reference module (float32 CPU) and the float64 oracle.
 Tolerance: <= 1e-4 max-abs on pre-clamp outputs and intermediates."""
 import os
@@ -23,7 +23,7 @@ def close(a, b, msg, atol=TOL, rtol=1e-5):
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=msg)
 
 
-def test_conv_kernel_vs_torch_reference():
+def test_conv_kernel_vs_torch_reference(conv_mode):
     """ct_conv2d_f32 against a plain float64 torch conv on the CPU, all epilogue variants and edge sizes."""
     import ct_hip
     import torch.nn.functional as F
@@ -46,7 +46,7 @@ def test_conv_kernel_vs_torch_reference():
 
 
 @pytest.mark.parametrize("name", ["a", "b"])
-def test_forward_vs_reference_small(golden_dir, name):
+def test_forward_vs_reference_small(golden_dir, name, conv_mode):
     g = _g(golden_dir, "dcmcs3di_small.npz")
     m = build_model().cuda()
     left, right = torch.from_numpy(g[name + "/left"]).cuda(), torch.from_numpy(g[name + "/right"]).cuda()
@@ -77,7 +77,7 @@ def test_forward_vs_reference_small(golden_dir, name):
     assert valid2[1].dtype == torch.bool
 
 
-def test_forward_shallow_batch2_vs_reference(golden_dir):
+def test_forward_shallow_batch2_vs_reference(golden_dir, conv_mode):
     g = _g(golden_dir, "dcmcs3di_shallow.npz")
     m = build_model(seed=3, extraction_layers=2, transfer_layers=1, channels=64).cuda()
     p = m.forward_parts(torch.from_numpy(g["left"]).cuda(), torch.from_numpy(g["right"]).cuda())
@@ -86,7 +86,7 @@ def test_forward_shallow_batch2_vs_reference(golden_dir):
     close(p["colsum_left"][:, 0].cpu().numpy(), g["colsum"], "colsum")
 
 
-def test_forward_vs_oracle_odd_size_and_load_state_dict():
+def test_forward_vs_oracle_odd_size_and_load_state_dict(conv_mode):
     """A size that is no multiple of the 4x32 tile, weights moved through state_dict (checkpoint path)."""
     src = build_model(seed=5, extraction_layers=3, transfer_layers=2)
     m = build_model(seed=6, extraction_layers=3, transfer_layers=2).cuda()

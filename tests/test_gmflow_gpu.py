@@ -26,7 +26,7 @@ def build(g):
 
 
 @pytest.mark.parametrize("tag,hw,seed", [("a", (135, 240), 1), ("b", (96, 128), 2)])
-def test_gmflow_vs_reference(golden_dir, tag, hw, seed):
+def test_gmflow_vs_reference(golden_dir, tag, hw, seed, conv_mode):
     from oracle.gmflow import derive_matcher_inference_size
     g = _g(golden_dir)
     m = build(g)

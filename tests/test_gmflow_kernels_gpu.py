@@ -36,7 +36,7 @@ def rnd(*shape):
     # multi-tile / multi-group geometries of the LDS-tiled stride-1 path (persistent schedule, 16-byte I/O)
     (2, 96, 96, 40, 72, 3, 3, 1, 1, 1), (1, 130, 256, 24, 64, 3, 3, 1, 1, 1), (3, 384, 128, 20, 68, 1, 5, 1, 0, 2),
     (3, 384, 128, 21, 68, 5, 1, 1, 2, 0), (2, 64, 192, 17, 100, 1, 1, 1, 0, 0)])
-def test_gconv(hip, cfg):
+def test_gconv(hip, cfg, conv_mode):
     n, cin, cout, h, w, kh, kw, s, ph, pw = cfg
     x, wt, b = rnd(n, cin, h, w), rnd(cout, cin, kh, kw) / (cin * kh * kw) ** 0.5, rnd(cout)
     ref = F.conv2d(x.double(), wt.double(), b.double(), stride=s, padding=(ph, pw))
