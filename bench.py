@@ -167,7 +167,7 @@ def main():
                          "GB/s": ALGO_BYTES_PER_PAIR * value / world / 1e9,
                          "frac_of_peak": ALGO_BYTES_PER_PAIR * value / world / HBM_PEAK}}
 
-        if not args.no_extra:
+        if not args.no_extra and world == 1:        # informational rates of the other paths: single-GPU runs only
             def rate(fn, n=10):
                 fn()
                 torch.cuda.synchronize()
@@ -241,8 +241,9 @@ def main():
                        "sharding": "frame f -> rank f % world; one all_gather of per-frame Lab stats"},
             "roofline": roof, "cpu_baseline": cpu, "extra": extra,
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()                              # rank 0 is still measuring its roofline while the others arrive here
         dist.destroy_process_group()
 
 
