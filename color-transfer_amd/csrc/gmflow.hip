@@ -223,6 +223,59 @@ __global__ void eltwise_kernel(const float *__restrict__ a, const float *__restr
 }
 
 // =================================================================================================
+// NCHW <-> token rows: rows[(b*H + y)*W + x][c0 + c] = nchw[b][c][y][x]  (and back).  The streaming parallax attention
+// works on channels-last rows; torch's permute().contiguous() moves these tensors at < 1 TB/s.  One workgroup per
+// (64 pixels of a row, b*H + y): 32-channel x 64-pixel tiles through LDS, 256-byte runs on the NCHW side, 128-byte
+// runs on the row side.  grid = (ceil(W/64), B*H), block 256.
+// =================================================================================================
+template <bool TO_ROWS>
+__global__ __launch_bounds__(256) void rows_transpose_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int H,
+                                                             int W, long long nchw_bstride, int row_channels, int c0) {
+    __shared__ float t[32][65];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * 64;
+    const int by = blockIdx.y, b = by / H, y = by - b * H;
+    const size_t plane = (size_t)H * W;
+    const float *nsrc = src;
+    float *ndst = dst;
+    for (int cb = 0; cb < C; cb += 32) {
+        if (TO_ROWS) {
+            // NCHW -> LDS: thread (c = tid>>3 [+0], x = 8*(tid&7)..) : 32 channels x 64 pixels, 8 floats per thread
+            const int c = tid >> 3, xs = (tid & 7) * 8;
+            const float *p = nsrc + (size_t)b * nchw_bstride + (size_t)(cb + c) * plane + (size_t)y * W + x0 + xs;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t[c][xs + i] = (cb + c < C && x0 + xs + i < W) ? p[i] : 0.f;
+            __syncthreads();
+            // LDS -> rows: thread (x = tid>>2, channel group g = tid&3 -> 8 channels)
+            const int x = tid >> 2, g = (tid & 3) * 8;
+            if (x0 + x < W) {
+                float *q = ndst + ((size_t)by * W + x0 + x) * row_channels + c0 + cb + g;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (cb + g + i < C) q[i] = t[g + i][x];
+            }
+            __syncthreads();
+        } else {
+            const int x = tid >> 2, g = (tid & 3) * 8;
+            if (x0 + x < W) {
+                const float *q = nsrc + ((size_t)by * W + x0 + x) * row_channels + c0 + cb + g;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t[g + i][x] = (cb + g + i < C) ? q[i] : 0.f;
+            }
+            __syncthreads();
+            const int c = tid >> 3, xs = (tid & 7) * 8;
+            if (cb + c < C) {
+                float *p = ndst + (size_t)b * nchw_bstride + (size_t)(cb + c) * plane + (size_t)y * W + x0 + xs;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (x0 + xs + i < W) p[i] = t[c][xs + i];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// =================================================================================================
 // nn.Linear on channels-last tokens: out[t][n] = act( sum_k x[t][k] W[n][k] + bias[n] )
 // LDS-tiled "NT" GEMM: a workgroup owns 128 tokens x 128 features, each of its 4 waves a 64 x 64 quarter (2 x 2 MFMA
 // tiles).  K is walked in 32-channel chunks: both operands are K-contiguous in memory ([T][K] and PyTorch's [N][K]),
@@ -1093,6 +1146,26 @@ int ct_linear_tokens_f32(const float *x, const float *x2, int k1, const float *w
     if (tokens == 0) return CT_OK;
     dim3 grid((unsigned)((tokens + 127) / 128), (n + 127) / 128);
     hipLaunchKernelGGL(ct::linear_tokens_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, x2, k1, w, bias, out, tokens, k, n, act);
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+}
+
+int ct_nchw_to_rows_f32(const float *nchw, float *rows, int batch, int c, int h, int w, long long nchw_bstride, int row_channels,
+                        int c0, void *stream) {
+    if (!nchw || !rows || batch < 0 || c < 1 || h < 1 || w < 1 || c0 < 0 || c0 + c > row_channels) return CT_E_BADARG;
+    if (batch == 0) return CT_OK;
+    hipLaunchKernelGGL((ct::rows_transpose_kernel<true>), dim3((w + 63) / 64, batch * h), dim3(256), 0, (hipStream_t)stream, nchw,
+                       rows, c, h, w, nchw_bstride, row_channels, c0);
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+}
+
+int ct_rows_to_nchw_f32(const float *rows, float *nchw, int batch, int c, int h, int w, long long nchw_bstride, int row_channels,
+                        int c0, void *stream) {
+    if (!nchw || !rows || batch < 0 || c < 1 || h < 1 || w < 1 || c0 < 0 || c0 + c > row_channels) return CT_E_BADARG;
+    if (batch == 0) return CT_OK;
+    hipLaunchKernelGGL((ct::rows_transpose_kernel<false>), dim3((w + 63) / 64, batch * h), dim3(256), 0, (hipStream_t)stream, rows,
+                       nchw, c, h, w, nchw_bstride, row_channels, c0);
     CT_CHECK_LAUNCH();
     return CT_OK;
 }

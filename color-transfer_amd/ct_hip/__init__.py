@@ -477,6 +477,8 @@ SIGNATURES.update({
     "ct_attention_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int, _c_int, _c_int]),
     "ct_attention_tokens_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_int, _c_p,
                                          ctypes.c_size_t, _c_p]),
+    "ct_nchw_to_rows_f32": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_ll, _c_int, _c_int, _c_p]),
+    "ct_rows_to_nchw_f32": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_ll, _c_int, _c_int, _c_p]),
     "ct_attention_rows64_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_f, _c_p]),
     "ct_attention_colsum64_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_f, _c_p]),
     "ct_local_corr_softmax_f32": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
@@ -677,17 +679,26 @@ def pam_streaming(q, k, v, rgb, q_other, k_other):
         raise CtHipError("pam_streaming is built for 64 channels")
     scale = 1.0 / c                                   # the reference scales by 1/c, not 1/sqrt(c) (attention.py:41)
 
-    def rows(t):                                      # [B,C,H,W] -> [B*H, W, C] tokens (data movement only)
-        return t.permute(0, 2, 3, 1).reshape(b * h, w, t.shape[1]).contiguous()
+    def rows(t, out=None, c0=0):                      # [B,C,H,W] -> [B*H, W, C] tokens (data movement only)
+        ct = t.shape[1]
+        if out is None:
+            out = torch.empty((b * h, w, ct), dtype=torch.float32, device=t.device)
+        check(lib().ct_nchw_to_rows_f32(_ptr(t), _ptr(out), b, ct, h, w, _nchw_bstride(t), out.shape[2], c0, _stream()))
+        return out
+
+    def nchw(t, ct, c0):                              # [B*H, W, C'] tokens -> [B,ct,H,W] from channels c0..c0+ct
+        out = torch.empty((b, ct, h, w), dtype=torch.float32, device=t.device)
+        check(lib().ct_rows_to_nchw_f32(_ptr(t), _ptr(out), b, ct, h, w, ct * h * w, t.shape[2], c0, _stream()))
+        return out
     qt, kt = rows(q), rows(k)
-    vt = torch.zeros((b * h, w, 96), dtype=torch.float32, device=q.device)
-    vt[:, :, :64] = rows(v)
-    vt[:, :, 64:67] = rows(rgb)
+    vt = torch.empty((b * h, w, 96), dtype=torch.float32, device=q.device)
+    vt[:, :, 67:] = 0.0                               # the 29 padding channels of the 96-channel value
+    rows(v, vt, 0)
+    rows(rgb, vt, 64)
     out = torch.empty((b * h, w, 96), dtype=torch.float32, device=q.device)
     check(lib().ct_attention_rows64_f32(_ptr(qt), _ptr(kt), _ptr(vt), _ptr(out), _c_p(0), b * h, w, scale, _stream()))
-    out = out.view(b, h, w, 96)
-    fea = out[..., :64].permute(0, 3, 1, 2).contiguous()
-    wrgb = out[..., 64:67].permute(0, 3, 1, 2).contiguous()
+    fea = nchw(out, 64, 0)
+    wrgb = nchw(out, 3, 64)
     qo, ko = rows(q_other), rows(k_other)
     stats = torch.empty((b * h, w, 2), dtype=torch.float32, device=q.device)
     check(lib().ct_attention_rows64_f32(_ptr(qo), _ptr(ko), _c_p(0), _c_p(0), _ptr(stats), b * h, w, scale, _stream()))

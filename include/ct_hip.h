@@ -248,6 +248,12 @@ int ct_attention_tokens_f32(const float *q, const float *k, const float *v, cons
  *                             statistics stats[b][i] = (max, sum) of that softmax (v == NULL: statistics only)
  *   ct_attention_colsum64_f32: colsum[b][j] = sum_i exp(q_i.k_j*scale - max_i) / sum_i  (the valid-mask numerator),
  *                             fixed summation order.  batch = N*H rows, len = W, tokens channels-last.                */
+/* layout moves for the row attention: rows[(b*h + y)*w + x][c0 + ch] = nchw[b][ch][y][x] for ch < c (row_channels
+ * floats per token in `rows`), and back.  nchw_bstride: elements between images (channel slices are fine).           */
+int ct_nchw_to_rows_f32(const float *nchw, float *rows, int batch, int c, int h, int w, long long nchw_bstride,
+                        int row_channels, int c0, void *stream);
+int ct_rows_to_nchw_f32(const float *rows, float *nchw, int batch, int c, int h, int w, long long nchw_bstride,
+                        int row_channels, int c0, void *stream);
 int ct_attention_rows64_f32(const float *q, const float *k, const float *v, float *out, float *stats,
                             int batch, int len, float scale, void *stream);
 int ct_attention_colsum64_f32(const float *q, const float *k, const float *stats, float *colsum,
