@@ -737,44 +737,82 @@ __global__ __launch_bounds__(256) void attention_colsum_kernel(const float *__re
                                                                const float *__restrict__ stats, float *__restrict__ colsum, int L,
                                                                float scale) {
     constexpr int CH = C / 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nl = lane & 31, hl = lane >> 5;
+    constexpr int QLD = C + 4;                      // padded LDS rows: conflict-free 16-byte column reads
+    constexpr int QV4 = (32 * C / 4) / 256;         // float4 per thread of one query tile
+    // The 4 waves of a workgroup hold 4 x 32 keys of the SAME row and sweep the same queries: every 32-query tile of Q
+    // and its (max, 1/sum) statistics are fetched once per workgroup (next tile in flight in registers), staged in LDS
+    // and read from there as the MFMA A operand.  Scores live in the log2 domain: p = exp2(s' - m') * (1/l).
+    __shared__ float Qs[32 * QLD];
+    __shared__ float2 Ms[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, hl = lane >> 5;
     const int b = blockIdx.y;
     const int j0 = (blockIdx.x * 4 + wave) * 32;
-    if (j0 >= L) return;
     const size_t tb = (size_t)b * L;
     const int kj = j0 + nl;
-    float kb[CH];                                   // B operand: this lane's key row
+    float kb[CH];                                   // B operand: this lane's key row (a workgroup's surplus waves clamp)
     {
+        const float qs = scale * kLog2e;
         const float *kp = k + (tb + (kj < L ? kj : L - 1)) * C + hl * CH;
 #pragma unroll
         for (int i = 0; i < CH / 4; ++i) {
             const float4 t = *reinterpret_cast<const float4 *>(kp + 4 * i);
-            kb[4 * i] = t.x * scale; kb[4 * i + 1] = t.y * scale; kb[4 * i + 2] = t.z * scale; kb[4 * i + 3] = t.w * scale;
+            kb[4 * i] = t.x * qs; kb[4 * i + 1] = t.y * qs; kb[4 * i + 2] = t.z * qs; kb[4 * i + 3] = t.w * qs;
         }
     }
+    float4 qpre[QV4];
+    float2 mpre = make_float2(0.f, 0.f);
+    auto fetch = [&](int i0) {
+#pragma unroll
+        for (int i = 0; i < QV4; ++i) {
+            const int f = tid + i * 256, qq = f / (C / 4), c4 = f - qq * (C / 4);
+            qpre[i] = (i0 + qq < L) ? *reinterpret_cast<const float4 *>(q + (tb + i0 + qq) * C + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (tid < 32) {
+            // an out-of-range query contributes exp2(0 - inf) * 0 = 0
+            mpre = (i0 + tid < L) ? *reinterpret_cast<const float2 *>(stats + (tb + i0 + tid) * 2) : make_float2(INFINITY, INFINITY);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < QV4; ++i) {
+            const int f = tid + i * 256, qq = f / (C / 4), c4 = f - qq * (C / 4);
+            *reinterpret_cast<float4 *>(Qs + qq * QLD + 4 * c4) = qpre[i];
+        }
+        if (tid < 32) Ms[tid] = make_float2(mpre.x * kLog2e, 1.0f / mpre.y);   // (max in log2 units, 1 / sum)
+    };
     float acc = 0.f;
+    fetch(0);
+    stage();
+    __syncthreads();
     for (int i0 = 0; i0 < L; i0 += 32) {
-        const int qi = i0 + nl;
-        const float *qp = q + (tb + (qi < L ? qi : L - 1)) * C + hl * CH;
+        const bool more = i0 + 32 < L;
+        if (more) fetch(i0 + 32);
         f32x16g s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        const float *qp = Qs + nl * QLD + hl * CH;
+        float4 tc = *reinterpret_cast<const float4 *>(qp), tn = tc;
 #pragma unroll
         for (int i = 0; i < CH / 4; ++i) {
-            const float4 t = *reinterpret_cast<const float4 *>(qp + 4 * i);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(t.x, kb[4 * i], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(t.y, kb[4 * i + 1], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(t.z, kb[4 * i + 2], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(t.w, kb[4 * i + 3], s, 0, 0, 0);
+            if (i + 1 < CH / 4) tn = *reinterpret_cast<const float4 *>(qp + 4 * (i + 1));
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(tc.x, kb[4 * i], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(tc.y, kb[4 * i + 1], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(tc.z, kb[4 * i + 2], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(tc.w, kb[4 * i + 3], s, 0, 0, 0);
+            tc = tn;
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
-        // lane: key nl; s[r] = score of query i0 + (r&3)+8(r>>2)+4hl
+        // lane: key nl; s[r] = log2-domain score of query i0 + (r&3)+8(r>>2)+4hl
+        float2 ml[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qq = i0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-            if (qq < L) {
-                const float2 ml = *reinterpret_cast<const float2 *>(stats + (tb + qq) * 2);
-                acc += expf(s[r] - ml.x) / ml.y;
-            }
+        for (int r = 0; r < 16; ++r) ml[r] = Ms[(r & 3) + 8 * (r >> 2) + 4 * hl];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc = fmaf(__builtin_amdgcn_exp2f(s[r] - ml[r].x), ml[r].y, acc);
+        __syncthreads();                 // every wave is done with this tile
+        if (more) {
+            stage();
+            __syncthreads();
         }
     }
     acc += __shfl_xor(acc, 32, 64);
