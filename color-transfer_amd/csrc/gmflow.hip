@@ -469,7 +469,43 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(const float *__r
 // =================================================================================================
 constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
 
-template <int C, int CV, bool MAP>
+// ---- split-bf16 scores (SS = true): the q.k products of the 64-channel row attention on the bf16 matrix pipe with
+// float32-grade accuracy -- three bf16 pieces per operand, six v_mfma_f32_32x32x16_bf16 per K step of 16 channels, float32
+// accumulation (arithmetic and error bound as in conv_split.hip).  The P.V product stays on the f32 MFMA.
+typedef __bf16 bf16x8g __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2g __attribute__((ext_vector_type(2)));
+typedef float f32x2g __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int pack_bf16g(float a, float b) {
+    f32x2g v = {a, b};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2g));
+}
+__device__ __forceinline__ void split3x2g(float x0, float x1, unsigned int &hw, unsigned int &mw, unsigned int &lw) {
+    hw = pack_bf16g(x0, x1);
+    const float r0 = x0 - __uint_as_float(hw << 16), r1 = x1 - __uint_as_float(hw & 0xffff0000u);
+    mw = pack_bf16g(r0, r1);
+    lw = pack_bf16g(r0 - __uint_as_float(mw << 16), r1 - __uint_as_float(mw & 0xffff0000u));
+}
+// eight consecutive floats -> the three 16-byte bf16 fragments (hi, mid, lo)
+__device__ __forceinline__ void split3x8g(const float (&x)[8], uint4 &h, uint4 &m, uint4 &l) {
+    unsigned int hw[4], mw[4], lw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split3x2g(x[2 * i], x[2 * i + 1], hw[i], mw[i], lw[i]);
+    h = make_uint4(hw[0], hw[1], hw[2], hw[3]); m = make_uint4(mw[0], mw[1], mw[2], mw[3]); l = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+}
+// s += A . B with A, B given as (hi, mid, lo) fragments; small terms first
+__device__ __forceinline__ void mfma_split6(f32x16g &s, const uint4 (&a)[3], const uint4 (&b)[3]) {
+    const bf16x8g ah = __builtin_bit_cast(bf16x8g, a[0]), am = __builtin_bit_cast(bf16x8g, a[1]), al = __builtin_bit_cast(bf16x8g, a[2]);
+    const bf16x8g bh = __builtin_bit_cast(bf16x8g, b[0]), bm = __builtin_bit_cast(bf16x8g, b[1]), bl = __builtin_bit_cast(bf16x8g, b[2]);
+    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, s, 0, 0, 0);
+}
+constexpr int kSsRow(int C) { return 2 * C + 16; }   // bytes per LDS row of a split tile: 16-byte fragment reads are conflict free
+
+template <int C, int CV, bool MAP, bool SS>
 __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                                const float *__restrict__ v, const int *__restrict__ region,
                                                                const int *__restrict__ rowmap, float *__restrict__ out,
@@ -484,7 +520,8 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
     // The 4 waves of a workgroup attend 4 x 32 queries of the SAME batch item to the same keys: every 32-key tile
     // of K and V is fetched once per workgroup with 16-byte loads (next tile in flight in registers while the current
     // one is multiplied), staged in LDS, and read from there as MFMA operands.
-    __shared__ float Ks[32 * KLD];
+    constexpr int SROW = kSsRow(C);                 // SS: K tile as [piece][key][C] bf16, rows padded to SROW bytes
+    __shared__ __attribute__((aligned(16))) float Ks[SS ? 3 * 32 * SROW / 4 : 32 * KLD];
     __shared__ float Vs[32 * VLD];
     __shared__ int Rs[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, hl = lane >> 5;
@@ -501,9 +538,18 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
         else return tb + i;
     };
     // B operand of S^T = K Q^T : lane (query nl, half hl) holds q[query][hl*C/2 + p], p < C/2
-    float qb[CH];
+    float qb[SS ? 1 : CH];
+    uint4 qf[SS ? C / 16 : 1][3];      // SS: B fragments, K step s = channels 16 s + 8 hl + j
     const float qs = scale * kLog2e;   // scores live in the log2 domain: softmax through v_exp_f32 (2^x) directly
-    {
+    if constexpr (SS) {
+        const float *qp = q + row(qclamp) * C + 8 * hl;
+#pragma unroll
+        for (int st = 0; st < C / 16; ++st) {
+            const float4 t0 = *reinterpret_cast<const float4 *>(qp + 16 * st), t1 = *reinterpret_cast<const float4 *>(qp + 16 * st + 4);
+            const float x[8] = {t0.x * qs, t0.y * qs, t0.z * qs, t0.w * qs, t1.x * qs, t1.y * qs, t1.z * qs, t1.w * qs};
+            split3x8g(x, qf[st][0], qf[st][1], qf[st][2]);
+        }
+    } else {
         const float *qp = q + row(qclamp) * C + hl * CH;
 #pragma unroll
         for (int i = 0; i < CH / 4; ++i) {
@@ -562,7 +608,17 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
 #pragma unroll
         for (int i = 0; i < KV4; ++i) {
             const int f = tid + i * 256, key = f / (C / 4), c4 = f - key * (C / 4);
-            *reinterpret_cast<float4 *>(Ks + key * KLD + 4 * c4) = kpre[i];
+            if constexpr (SS) {
+                unsigned int h0, m0, l0, h1, m1, l1;
+                split3x2g(kpre[i].x, kpre[i].y, h0, m0, l0);
+                split3x2g(kpre[i].z, kpre[i].w, h1, m1, l1);
+                unsigned char *kd = reinterpret_cast<unsigned char *>(Ks) + key * SROW + 8 * c4;
+                *reinterpret_cast<uint2 *>(kd) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2 *>(kd + 32 * SROW) = make_uint2(m0, m1);
+                *reinterpret_cast<uint2 *>(kd + 64 * SROW) = make_uint2(l0, l1);
+            } else {
+                *reinterpret_cast<float4 *>(Ks + key * KLD + 4 * c4) = kpre[i];
+            }
         }
         if constexpr (CV >= 32) {
 #pragma unroll
@@ -607,6 +663,22 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
         f32x16g s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        if constexpr (SS) {
+            const unsigned char *kp = reinterpret_cast<const unsigned char *>(Ks) + nl * SROW + 16 * hl;
+            uint4 ac[3], an[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) ac[p] = *reinterpret_cast<const uint4 *>(kp + p * 32 * SROW);
+#pragma unroll
+            for (int st = 0; st < C / 16; ++st) {
+                if (st + 1 < C / 16) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) an[p] = *reinterpret_cast<const uint4 *>(kp + p * 32 * SROW + 32 * (st + 1));
+                }
+                mfma_split6(s, ac, qf[st]);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) ac[p] = an[p];
+            }
+        } else {
         const float *kp = Ks + nl * KLD + hl * CH;
         float4 tc = *reinterpret_cast<const float4 *>(kp), tn = tc;
 #pragma unroll
@@ -619,6 +691,7 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
             tc = tn;
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the LDS read of group i+1
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // the MFMAs of group i
+        }
         }
         // lane: query nl; s[r] = log2-domain score of key j0 + (r&3)+8(r>>2)+4hl (q carries scale * log2(e))
         if (region) {                                    // shifted-window mask, one uniform branch per tile
@@ -736,27 +809,27 @@ template <int C>
 __global__ __launch_bounds__(256) void attention_colsum_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                                const float *__restrict__ stats, float *__restrict__ colsum, int L,
                                                                float scale) {
-    constexpr int CH = C / 2;
-    constexpr int QLD = C + 4;                      // padded LDS rows: conflict-free 16-byte column reads
     constexpr int QV4 = (32 * C / 4) / 256;         // float4 per thread of one query tile
     // The 4 waves of a workgroup hold 4 x 32 keys of the SAME row and sweep the same queries: every 32-query tile of Q
     // and its (max, 1/sum) statistics are fetched once per workgroup (next tile in flight in registers), staged in LDS
     // and read from there as the MFMA A operand.  Scores live in the log2 domain: p = exp2(s' - m') * (1/l).
-    __shared__ float Qs[32 * QLD];
+    constexpr int SROW = kSsRow(C);                 // Q tile as [piece][query][C] bf16 (split-bf16 scores, see mfma_split6)
+    __shared__ __attribute__((aligned(16))) unsigned char Qs[3 * 32 * SROW];
     __shared__ float2 Ms[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, hl = lane >> 5;
     const int b = blockIdx.y;
     const int j0 = (blockIdx.x * 4 + wave) * 32;
     const size_t tb = (size_t)b * L;
     const int kj = j0 + nl;
-    float kb[CH];                                   // B operand: this lane's key row (a workgroup's surplus waves clamp)
+    uint4 kf[C / 16][3];                            // B fragments: this lane's key row (a workgroup's surplus waves clamp)
     {
         const float qs = scale * kLog2e;
-        const float *kp = k + (tb + (kj < L ? kj : L - 1)) * C + hl * CH;
+        const float *kp = k + (tb + (kj < L ? kj : L - 1)) * C + 8 * hl;
 #pragma unroll
-        for (int i = 0; i < CH / 4; ++i) {
-            const float4 t = *reinterpret_cast<const float4 *>(kp + 4 * i);
-            kb[4 * i] = t.x * qs; kb[4 * i + 1] = t.y * qs; kb[4 * i + 2] = t.z * qs; kb[4 * i + 3] = t.w * qs;
+        for (int st = 0; st < C / 16; ++st) {
+            const float4 t0 = *reinterpret_cast<const float4 *>(kp + 16 * st), t1 = *reinterpret_cast<const float4 *>(kp + 16 * st + 4);
+            const float x[8] = {t0.x * qs, t0.y * qs, t0.z * qs, t0.w * qs, t1.x * qs, t1.y * qs, t1.z * qs, t1.w * qs};
+            split3x8g(x, kf[st][0], kf[st][1], kf[st][2]);
         }
     }
     float4 qpre[QV4];
@@ -776,7 +849,13 @@ __global__ __launch_bounds__(256) void attention_colsum_kernel(const float *__re
 #pragma unroll
         for (int i = 0; i < QV4; ++i) {
             const int f = tid + i * 256, qq = f / (C / 4), c4 = f - qq * (C / 4);
-            *reinterpret_cast<float4 *>(Qs + qq * QLD + 4 * c4) = qpre[i];
+            unsigned int h0, m0, l0, h1, m1, l1;
+            split3x2g(qpre[i].x, qpre[i].y, h0, m0, l0);
+            split3x2g(qpre[i].z, qpre[i].w, h1, m1, l1);
+            unsigned char *qd = Qs + qq * SROW + 8 * c4;
+            *reinterpret_cast<uint2 *>(qd) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2 *>(qd + 32 * SROW) = make_uint2(m0, m1);
+            *reinterpret_cast<uint2 *>(qd + 64 * SROW) = make_uint2(l0, l1);
         }
         if (tid < 32) Ms[tid] = make_float2(mpre.x * kLog2e, 1.0f / mpre.y);   // (max in log2 units, 1 / sum)
     };
@@ -790,18 +869,19 @@ __global__ __launch_bounds__(256) void attention_colsum_kernel(const float *__re
         f32x16g s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
-        const float *qp = Qs + nl * QLD + hl * CH;
-        float4 tc = *reinterpret_cast<const float4 *>(qp), tn = tc;
+        const unsigned char *qp = Qs + nl * SROW + 16 * hl;
+        uint4 ac[3], an[3];
 #pragma unroll
-        for (int i = 0; i < CH / 4; ++i) {
-            if (i + 1 < CH / 4) tn = *reinterpret_cast<const float4 *>(qp + 4 * (i + 1));
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(tc.x, kb[4 * i], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(tc.y, kb[4 * i + 1], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(tc.z, kb[4 * i + 2], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(tc.w, kb[4 * i + 3], s, 0, 0, 0);
-            tc = tn;
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        for (int p = 0; p < 3; ++p) ac[p] = *reinterpret_cast<const uint4 *>(qp + p * 32 * SROW);
+#pragma unroll
+        for (int st = 0; st < C / 16; ++st) {
+            if (st + 1 < C / 16) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) an[p] = *reinterpret_cast<const uint4 *>(qp + p * 32 * SROW + 32 * (st + 1));
+            }
+            mfma_split6(s, ac, kf[st]);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) ac[p] = an[p];
         }
         // lane: key nl; s[r] = log2-domain score of query i0 + (r&3)+8(r>>2)+4hl
         float2 ml[16];
@@ -1231,7 +1311,7 @@ int ct_attention_tokens_f32(const float *q, const float *k, const float *v, cons
     if (batch == 0) return CT_OK;
     dim3 grid((len + 127) / 128, batch, nsplit);
     float *nostats = nullptr;
-#define CT_ATT(CVV, MAPPED) hipLaunchKernelGGL((ct::attention_tokens_kernel<128, CVV, MAPPED>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, region, rowmap, out, nostats, len, scale, ws)
+#define CT_ATT(CVV, MAPPED) hipLaunchKernelGGL((ct::attention_tokens_kernel<128, CVV, MAPPED, false>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, region, rowmap, out, nostats, len, scale, ws)
     if (cv == 128) { if (rowmap) CT_ATT(128, true); else CT_ATT(128, false); }
     else { if (rowmap) CT_ATT(2, true); else CT_ATT(2, false); }
 #undef CT_ATT
@@ -1253,8 +1333,8 @@ int ct_attention_rows64_f32(const float *q, const float *k, const float *v, floa
     dim3 grid((len + 127) / 128, batch);
     const int *noreg = nullptr;
     if (v && (reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(out)) & 15) return CT_E_ALIGN;
-    if (v) hipLaunchKernelGGL((ct::attention_tokens_kernel<64, 96, false>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, noreg, noreg, out, stats, len, scale, (float *)nullptr);
-    else hipLaunchKernelGGL((ct::attention_tokens_kernel<64, 0, false>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, noreg, noreg, out, stats, len, scale, (float *)nullptr);
+    if (v) hipLaunchKernelGGL((ct::attention_tokens_kernel<64, 96, false, true>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, noreg, noreg, out, stats, len, scale, (float *)nullptr);
+    else hipLaunchKernelGGL((ct::attention_tokens_kernel<64, 0, false, true>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, noreg, noreg, out, stats, len, scale, (float *)nullptr);
     CT_CHECK_LAUNCH();
     return CT_OK;
 }
