@@ -84,9 +84,9 @@ __device__ __forceinline__ double linear_to_srgb(double u) {
     const double s0 = (double)hw_exp2((-1.0f / 12.0f) * hw_log2((float)u));
     const double s2 = s0 * s0;
     const double s4 = s2 * s2;
-    const double s8 = s4 * s4;
-    const double e = u * (s8 * s4);        // u s0^12 = (1+eps)^12
-    const double p = u * ((s4 * s2) * s0); // u s0^7
+    const double s5 = s4 * s0;
+    const double p = u * (s5 * s2);        // u s0^7
+    const double e = p * s5;               // u s0^12 = (1+eps)^12   (7 multiplications instead of 9)
     const double pw = p * fma(-7.0 / 12.0, e, 19.0 / 12.0);
     const double g = fma(1.055, pw, -0.055);
     const double lin = 12.92 * u;
