@@ -694,7 +694,7 @@ int ct_conv2d_f32(const float *in, const float *wp, const float *bias, const flo
     if ((ksize != 1 && ksize != 3) || (act != 0 && act != 1)) return CT_E_BADARG;
     if (n == 0 || h == 0 || w == 0) return CT_OK;
     ct::ConvArgs a;
-    a.in = in; a.wp = wp; a.bias = bias; a.residual = residual; a.out = out;
+    a.in = in; a.in2 = nullptr; a.cin1 = cin; a.in2_bstride = 0; a.wp = wp; a.bias = bias; a.residual = residual; a.out = out;
     a.cin = cin; a.cout = cout; a.H = h; a.W = w;
     a.in_bstride = in_bstride; a.out_bstride = out_bstride; a.res_bstride = res_bstride;
     a.act = act; a.clamp = clamp; a.groups = 1; a.prof = nullptr;
@@ -709,7 +709,7 @@ int ct_conv2d_f32(const float *in, const float *wp, const float *bias, const flo
 int ct_conv2d_prof_f32(const float *in, const float *wp, const float *bias, const float *residual, float *out, int n,
                        int cin, int cout, int h, int w, unsigned long long *prof, void *stream) {
     ct::ConvArgs a;
-    a.in = in; a.wp = wp; a.bias = bias; a.residual = residual; a.out = out;
+    a.in = in; a.in2 = nullptr; a.cin1 = cin; a.in2_bstride = 0; a.wp = wp; a.bias = bias; a.residual = residual; a.out = out;
     a.cin = cin; a.cout = cout; a.H = h; a.W = w;
     a.in_bstride = (long long)cin * h * w; a.out_bstride = (long long)cout * h * w; a.res_bstride = a.out_bstride;
     a.act = 0; a.clamp = 0; a.groups = 1; a.prof = prof;

@@ -116,7 +116,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
         const int t = (blockIdx.x + k * gridDim.x) / a.groups;
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
         const int x0 = tx * kSpTW, y0 = ty * kSpTH, c0 = chunk * kSpKC;
-        const float *in = a.in + (size_t)n * a.in_bstride + (size_t)c0 * plane;
+        // two-source input: a 16-channel chunk lies entirely in one of the tensors (cin1 % 16 == 0)
+        const bool second = a.in2 && c0 >= a.cin1;
+        const float *in = second ? a.in2 + (size_t)n * a.in2_bstride + (size_t)(c0 - a.cin1) * plane
+                                 : a.in + (size_t)n * a.in_bstride + (size_t)c0 * plane;
         if (unit) {
             const int gy = y0 + u_row - PADY, gx = x0 + 4 * u_g;
             const bool ok = gy >= 0 && gy < a.H && gx < a.W;          // W % 4 == 0: all four columns or none
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
                 pf4[j] = v;
             }
         }
-        if (HALO) {
+        if constexpr (HALO) {
 #pragma unroll
             for (int j = 0; j < PFE; ++j) {
                 const int e = (NF - 1 - tid) + j * NF;            // the fetch threads without a unit take the halo first
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
                 dst[2 * PSZ + px] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
             }
         }
-        if (HALO) {
+        if constexpr (HALO) {
             unsigned short *t16 = reinterpret_cast<unsigned short *>(tin);
 #pragma unroll
             for (int j = 0; j < PFE; ++j) {
@@ -439,6 +442,7 @@ static int launch_split(const ConvArgs &a, int N, hipStream_t s) {
 // 1 = this geometry / alignment has no split-bf16 kernel (the caller uses the exact-f32 one)
 int conv_split(const ConvArgs &a, int N, int kh, int kw, bool gen, hipStream_t s) {
     const bool vec = (a.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.in) & 15) == 0) && (a.in_bstride % 4 == 0) &&
+                     (!a.in2 || (((reinterpret_cast<uintptr_t>(a.in2) & 15) == 0) && (a.in2_bstride % 4 == 0) && (a.cin1 % 16 == 0))) &&
                      ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0) && (a.out_bstride % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(a.wp) & 15) == 0) &&
                      (!a.residual || (((reinterpret_cast<uintptr_t>(a.residual) & 15) == 0) && (a.res_bstride % 4 == 0)));
@@ -459,13 +463,15 @@ int conv_split(const ConvArgs &a, int N, int kh, int kw, bool gen, hipStream_t s
 
 extern "C" {
 
-int ct_conv2d_split_f32(const float *in, const void *wp_split, const float *bias, const float *residual, float *out, int n, int cin,
-                        int cout, int h, int w, int kh, int kw, long long in_bstride, long long out_bstride,
-                        long long res_bstride, int act, int clamp, void *stream) {
+int ct_conv2d_split_f32(const float *in, const float *in2, int cin1, const void *wp_split, const float *bias, const float *residual,
+                        float *out, int n, int cin, int cout, int h, int w, int kh, int kw, long long in_bstride,
+                        long long in2_bstride, long long out_bstride, long long res_bstride, int act, int clamp, void *stream) {
     if (!in || !wp_split || !bias || !out || n < 0 || cin < 1 || cout < 1 || h < 0 || w < 0 || act < 0 || act > 4) return CT_E_BADARG;
+    if (in2 && (cin1 < 16 || cin1 >= cin || (cin1 % 16))) return CT_E_BADARG;
     if (n == 0 || h == 0 || w == 0) return CT_OK;
     ct::ConvArgs a;
-    a.in = in; a.wp = reinterpret_cast<const float *>(wp_split); a.bias = bias; a.residual = residual; a.out = out;
+    a.in = in; a.in2 = in2; a.cin1 = in2 ? cin1 : cin; a.in2_bstride = in2_bstride;
+    a.wp = reinterpret_cast<const float *>(wp_split); a.bias = bias; a.residual = residual; a.out = out;
     a.cin = cin; a.cout = cout; a.H = h; a.W = w;
     a.in_bstride = in_bstride; a.out_bstride = out_bstride; a.res_bstride = res_bstride;
     a.act = act; a.clamp = clamp; a.groups = (cout + 63) / 64; a.prof = nullptr;
@@ -477,7 +483,8 @@ int ct_conv2d_split_f32(const float *in, const void *wp_split, const float *bias
 int ct_conv2d_split_prof_f32(const float *in, const void *wp_split, const float *bias, const float *residual, float *out, int n,
                              int cin, int cout, int h, int w, unsigned long long *prof, void *stream) {
     ct::ConvArgs a;
-    a.in = in; a.wp = reinterpret_cast<const float *>(wp_split); a.bias = bias; a.residual = residual; a.out = out;
+    a.in = in; a.in2 = nullptr; a.cin1 = cin; a.in2_bstride = 0;
+    a.wp = reinterpret_cast<const float *>(wp_split); a.bias = bias; a.residual = residual; a.out = out;
     a.cin = cin; a.cout = cout; a.H = h; a.W = w;
     a.in_bstride = (long long)cin * h * w; a.out_bstride = (long long)cout * h * w; a.res_bstride = a.out_bstride;
     a.act = 0; a.clamp = 0; a.groups = (cout + 63) / 64; a.prof = prof;

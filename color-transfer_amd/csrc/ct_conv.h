@@ -6,6 +6,9 @@ namespace ct {
 
 struct ConvArgs {
     const float *in;
+    const float *in2;       // split kernel only: channels >= cin1 come from this tensor (torch.cat on dim 1 without the copy); or NULL
+    int cin1;               // channels of `in` when in2 != NULL (a multiple of 16)
+    long long in2_bstride;
     const float *wp;
     const float *bias;      // [MT*32], zero padded
     const float *residual;  // nullable, same shape/strides as out

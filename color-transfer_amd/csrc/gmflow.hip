@@ -1201,7 +1201,7 @@ int ct_gconv2d_f32(const float *in, const float *wp, const float *bias, float *o
     if (stride == 1 && pad_h == kh / 2 && pad_w == kw / 2 && (kh & 1) && (kw & 1) && bias) {
         // stride-1 "same" convolution: the LDS-tiled persistent kernel of cnn.hip (same weight layout)
         ct::ConvArgs f;
-        f.in = in; f.wp = wp; f.bias = bias; f.residual = nullptr; f.out = out;
+        f.in = in; f.in2 = nullptr; f.cin1 = cin; f.in2_bstride = 0; f.wp = wp; f.bias = bias; f.residual = nullptr; f.out = out;
         f.cin = cin; f.cout = cout; f.H = h; f.W = w;
         f.in_bstride = in_bstride; f.out_bstride = out_bstride; f.res_bstride = 0;
         f.act = act; f.clamp = 0; f.groups = a.coutp / 64; f.prof = nullptr;

@@ -324,8 +324,8 @@ SIGNATURES.update({
     "ct_conv2d_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ll, _c_ll,
                                _c_ll, _c_int, _c_int, _c_p]),
     "ct_pam_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
-    "ct_conv2d_split_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ll,
-                                     _c_ll, _c_ll, _c_int, _c_int, _c_p]),
+    "ct_conv2d_split_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                     _c_int, _c_ll, _c_ll, _c_ll, _c_ll, _c_int, _c_int, _c_p]),
     "ct_pam_attend_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "ct_pam_valid_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_sz, _c_p]),
 })
@@ -382,12 +382,14 @@ def _split_ok(x, out, residual, kh, kw, stride, ph, pw):
     return True
 
 
-def _conv_split(x, split, cout, kh, kw, act, residual, clamp, out):
+def _conv_split(x, split, cout, kh, kw, act, residual, clamp, out, x2=None):
     ws, b64 = split
-    n, cin, h, w = x.shape
+    n, cin1, h, w = x.shape
+    cin = cin1 + (x2.shape[1] if x2 is not None else 0)
     rs = _nchw_bstride(residual) if residual is not None else 0
-    check(lib().ct_conv2d_split_f32(_ptr(x), _ptr(ws), _ptr(b64), _opt(residual), _ptr(out), n, cin, cout, h, w, kh, kw,
-                                    _nchw_bstride(x), _nchw_bstride(out), rs, int(act), int(bool(clamp)), _stream()))
+    check(lib().ct_conv2d_split_f32(_ptr(x), _opt(x2), cin1, _ptr(ws), _ptr(b64), _opt(residual), _ptr(out), n, cin, cout, h, w,
+                                    kh, kw, _nchw_bstride(x), _nchw_bstride(x2) if x2 is not None else 0, _nchw_bstride(out),
+                                    rs, int(act), int(bool(clamp)), _stream()))
     return out
 
 
@@ -523,9 +525,20 @@ def pack_gconv_weight(weight, bias):
     return wp, b
 
 
-def gconv2d(x, wp, bias, cout, ksize, stride=1, padding=0, act=ACT_NONE, out=None):
+def gconv2d(x, wp, bias, cout, ksize, stride=1, padding=0, act=ACT_NONE, out=None, x2=None):
+    """x2: optional second input tensor whose channels follow x's (torch.cat([x, x2], 1) without the copy when the
+    split-bf16 kernel takes the convolution; otherwise the concatenation is materialised here)."""
     kh, kw = (ksize, ksize) if isinstance(ksize, int) else ksize
     ph, pw = (padding, padding) if isinstance(padding, int) else padding
+    if x2 is not None:
+        split = getattr(wp, "_ct_split", None)
+        n, c1, h, w = x.shape
+        if (split is not None and bias is not None and c1 % 16 == 0 and x2.data_ptr() % 16 == 0 and x2.stride(0) % 4 == 0 and
+                _split_ok(x, out if out is not None else x, None, kh, kw, stride, ph, pw)):
+            if out is None:
+                out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+            return _conv_split(x, split, cout, kh, kw, act, None, False, out, x2=x2)
+        x = torch.cat([x, x2], dim=1)
     n, cin, h, w = x.shape
     ho, wo = (h + 2 * ph - kh) // stride + 1, (w + 2 * pw - kw) // stride + 1
     if out is None:

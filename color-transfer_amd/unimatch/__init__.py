@@ -136,14 +136,14 @@ def _packed_conv(weight, bias):
     return hit[1]
 
 
-def _conv(m, x, act=ACT_NONE, stride=None, padding=None, weight=None):
-    """Conv2d module (or a bare weight) -> ct_gconv2d_f32"""
+def _conv(m, x, act=ACT_NONE, stride=None, padding=None, weight=None, x2=None, out=None):
+    """Conv2d module (or a bare weight) -> ct_gconv2d_f32; x2 = second input whose channels follow x's (no torch.cat)"""
     w = m.weight if weight is None else weight
     b = getattr(m, "bias", None) if weight is None else None
     wp, bp = _packed_conv(w, b)
     st = (m.stride[0] if weight is None else 1) if stride is None else stride
     pd = (tuple(m.padding) if weight is None else 1) if padding is None else padding
-    return ct_hip.gconv2d(x, wp, bp, w.shape[0], (w.shape[2], w.shape[3]), st, pd, act=act)
+    return ct_hip.gconv2d(x, wp, bp, w.shape[0], (w.shape[2], w.shape[3]), st, pd, act=act, x2=x2, out=out)
 
 
 def _lin(m, x, act=ACT_NONE, x2=None):
@@ -286,17 +286,21 @@ class GMFlow(nn.Module):
         return ct_hip.eltwise(0, f0, pos), ct_hip.eltwise(0, f1, pos)
 
     def _refine_iter(self, net, inp, corr, flow, want_mask):             # reg_refine.py:58-122
+        """The reference's torch.cat's (reg_refine.py:43,51,72,75,77) never materialise: convs read two tensors, and
+        `x = [inp | motion features | flow]` is one buffer that `enc.conv` writes its 126 channels into."""
         enc, gru = self.refine.encoder, self.refine.gru
         cor = _conv(enc.convc2, _conv(enc.convc1, corr, ACT_RELU), ACT_RELU)
         flo = _conv(enc.convf2, _conv(enc.convf1, flow, ACT_RELU), ACT_RELU)
-        out = _conv(enc.conv, torch.cat([cor, flo], dim=1), ACT_RELU)
-        x = torch.cat([inp, out, flow], dim=1)
+        b, _, hh, ww = inp.shape
+        x = torch.empty((b, 256, hh, ww), dtype=torch.float32, device=inp.device)
+        x[:, :128] = inp
+        _conv(enc.conv, cor, ACT_RELU, x2=flo, out=x[:, 128:254])
+        x[:, 254:] = flow
         h = net
         for suf in ("1", "2"):
-            hx = torch.cat([h, x], dim=1)
-            z = _conv(getattr(gru, "convz" + suf), hx, ACT_SIGMOID)
-            r = _conv(getattr(gru, "convr" + suf), hx, ACT_SIGMOID)
-            q = _conv(getattr(gru, "convq" + suf), torch.cat([ct_hip.eltwise(1, r, h), x], dim=1), ACT_TANH)
+            z = _conv(getattr(gru, "convz" + suf), h, ACT_SIGMOID, x2=x)
+            r = _conv(getattr(gru, "convr" + suf), h, ACT_SIGMOID, x2=x)
+            q = _conv(getattr(gru, "convq" + suf), ct_hip.eltwise(1, r, h), ACT_TANH, x2=x)
             h = ct_hip.eltwise(2, z, h, q)
         delta = _conv(self.refine.flow_head.conv2, _conv(self.refine.flow_head.conv1, h, ACT_RELU))
         mask = _conv(self.refine.mask[2], _conv(self.refine.mask[0], h, ACT_RELU)) if want_mask else None

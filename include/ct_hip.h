@@ -178,11 +178,13 @@ int ct_conv2d_f32(const float *in, const float *wp, const float *bias, const flo
  * ct_conv2d_f32).  Stride 1, padding k/2, kernel (kh,kw) in {3x3, 1x1, 1x5, 5x1}; w % 4 == 0; in / out / residual
  * 16-byte aligned with batch strides % 4 == 0 (CT_E_BADARG otherwise: use ct_conv2d_f32 / ct_gconv2d_f32 then).
  * wp_split: bf16 bit patterns [ceil(cout/64)][ceil(cin/16)][kh*kw][piece hi,mid,lo][m][k-half][cout%32][8 channels];
- * bias: zero padded to 64*ceil(cout/64).  act: 0 none, 1 LeakyReLU(0.01), 2 ReLU, 3 sigmoid, 4 tanh.                */
-int ct_conv2d_split_f32(const float *in, const void *wp_split, const float *bias, const float *residual,
-                        float *out, int n, int cin, int cout, int h, int w, int kh, int kw,
-                        long long in_bstride, long long out_bstride, long long res_bstride, int act, int clamp,
-                        void *stream);
+ * bias: zero padded to 64*ceil(cout/64).  act: 0 none, 1 LeakyReLU(0.01), 2 ReLU, 3 sigmoid, 4 tanh.
+ * in2 != NULL: input channels [cin1, cin) come from in2 (cin1 % 16 == 0) -- torch.cat([a, b], dim=1) without the copy
+ * (reg_refine.py:43,72,75: the GRU's hx / [r*h, x] and the motion encoder's [cor, flo]).                            */
+int ct_conv2d_split_f32(const float *in, const float *in2, int cin1, const void *wp_split, const float *bias,
+                        const float *residual, float *out, int n, int cin, int cout, int h, int w, int kh,
+                        int kw, long long in_bstride, long long in2_bstride, long long out_bstride,
+                        long long res_bstride, int act, int clamp, void *stream);
 
 /* Parallax attention, one direction (pasmnet/attention.py:39-41, utils.py:30, utils.py:123-125):
  *   P = softmax_j( sum_c q[c][h][i] k[c][h][j] / c ) ;  out_v[c][h][i] = sum_j P[i][j] v[c][h][j],

@@ -69,6 +69,13 @@ def test_conv_split_bf16(hip, cfg):
     close(out, (ref + res.double()).clamp(0, 1), "split conv + skip + clamp", atol=tol, rtol=0)
     hip._conv_split(x.cuda(), (ws, b64), cout, kh, kw, 2, res.cuda(), False, out)         # activation then skip
     close(out, torch.relu(ref) + res.double(), "split conv, relu, + skip", atol=tol, rtol=0)
+    if cin >= 48:                                  # two-source input == conv on torch.cat([a, b], 1)
+        c1 = 16 * (cin // 32)
+        xa, xb = x[:, :c1].contiguous().cuda(), x[:, c1:].contiguous().cuda()
+        hip._conv_split(xa, (ws, b64), cout, kh, kw, 2, None, False, out, x2=xb)
+        close(out, torch.relu(ref), "split conv on a two-source input", atol=tol, rtol=0)
+        wpg, bpg = hip.pack_gconv_weight(wt.cuda(), b.cuda())
+        close(hip.gconv2d(xa, wpg, bpg, cout, (kh, kw), 1, (kh // 2, kw // 2), act=2, x2=xb), torch.relu(ref), "gconv2d x2", atol=tol, rtol=0)
     # the exact-f32 kernel on the same operands: the two agree to float32 rounding level
     wp, bp = hip.pack_gconv_weight(wt.cuda(), b.cuda())
     hip.set_conv_mode("exact")
