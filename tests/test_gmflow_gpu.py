@@ -54,6 +54,23 @@ def test_gmflow_vs_reference(golden_dir, tag, hw, seed, conv_mode):
     assert (res["fwd_occ"].cpu().numpy() == g[tag + "/fwd_occ"]).mean() > 0.99
 
 
+def test_gmflow_full_size_bidirectional_symmetry(golden_dir):
+    """BASELINE.json's size (960x540 -> inference 512x896).  Size-independent property of the bidirectional call
+    (unimatch/__init__.py:138-150): the backward flow of (a, b) is the forward flow of (b, a); every kernel computes a
+    sample independently of its batch position and in a fixed order, so the two agree to the last bit."""
+    from methods.dmsct import DMSCT
+    g = _g(golden_dir)
+    m = build(g)
+    a, b = make_pair(7, 540, 960)
+    size = DMSCT.derive_matcher_inference_size((1, 3, 540, 960))
+    r_ab = m(a.cuda(), b.cuda(), inference_size=size, pred_bidir_flow=True, fwd_bwd_consistency_check=True)
+    r_ba = m(b.cuda(), a.cuda(), inference_size=size, pred_bidir_flow=True, fwd_bwd_consistency_check=True)
+    for k in ("flow", "flow_bwd"):
+        assert torch.isfinite(r_ab[k]).all() and tuple(r_ab[k].shape) == (1, 2, 540, 960)
+    assert torch.equal(r_ab["flow_bwd"], r_ba["flow"]) and torch.equal(r_ab["flow"], r_ba["flow_bwd"])
+    assert torch.equal(r_ab["bwd_occ"], r_ba["fwd_occ"])
+
+
 def test_gmflow_rejects_other_configurations(golden_dir):
     from unimatch import GMFlow
     m = GMFlow().cuda()
