@@ -285,16 +285,13 @@ class GMFlow(nn.Module):
         pos = _position_table(h // splits, w // splits, c // 2, f0.device).repeat(b, 1, splits, splits).contiguous()
         return ct_hip.eltwise(0, f0, pos), ct_hip.eltwise(0, f1, pos)
 
-    def _refine_iter(self, net, inp, corr, flow, want_mask):             # reg_refine.py:58-122
+    def _refine_iter(self, net, x, corr, flow, want_mask):               # reg_refine.py:58-122
         """The reference's torch.cat's (reg_refine.py:43,51,72,75,77) never materialise: convs read two tensors, and
         `x = [inp | motion features | flow]` is one buffer that `enc.conv` writes its 126 channels into."""
         enc, gru = self.refine.encoder, self.refine.gru
         cor = _conv(enc.convc2, _conv(enc.convc1, corr, ACT_RELU), ACT_RELU)
         flo = _conv(enc.convf2, _conv(enc.convf1, flow, ACT_RELU), ACT_RELU)
-        b, _, hh, ww = inp.shape
-        x = torch.empty((b, 256, hh, ww), dtype=torch.float32, device=inp.device)
-        x[:, :128] = inp
-        _conv(enc.conv, cor, ACT_RELU, x2=flo, out=x[:, 128:254])
+        _conv(enc.conv, cor, ACT_RELU, x2=flo, out=x[:, 128:254])       # x[:, :128] = inp is loop invariant (caller)
         x[:, 254:] = flow
         h = net
         for suf in ("1", "2"):
@@ -354,11 +351,13 @@ class GMFlow(nn.Module):
             if scale == 1:
                 t0_ori, t1_ori = _tokens(f0_ori), _tokens(f1_ori)
                 proj = ct_hip.eltwise(5, _conv(self.refine_proj, _nchw(t0, h, w)), plane=h * w, chans=256, split=128)
-                net0, inp = proj[:, :128].contiguous(), proj[:, 128:].contiguous()      # loop invariant (unimatch.py:318-323)
+                net0 = proj[:, :128].contiguous()                                        # loop invariant (unimatch.py:318-323)
+                xbuf = torch.empty((proj.shape[0], 256, h, w), dtype=torch.float32, device=proj.device)
+                xbuf[:, :128] = proj[:, 128:]                                            # inp; [128:254] motion features, [254:] flow
                 for it in range(num_reg_refine):
                     corr = ct_hip.local_corr_flow(t0_ori, t1_ori, flow, 4)
                     last = it == num_reg_refine - 1
-                    _, up_mask, dflow = self._refine_iter(net0, inp, corr, flow, want_mask=last)
+                    _, up_mask, dflow = self._refine_iter(net0, xbuf, corr, flow, want_mask=last)
                     flow = ct_hip.eltwise(0, flow, dflow)
                     if dbg is not None:
                         dbg["flow_refine_%d" % it] = flow
