@@ -76,6 +76,12 @@ def test_conv_split_bf16(hip, cfg):
         close(out, torch.relu(ref), "split conv on a two-source input", atol=tol, rtol=0)
         wpg, bpg = hip.pack_gconv_weight(wt.cuda(), b.cuda())
         close(hip.gconv2d(xa, wpg, bpg, cout, (kh, kw), 1, (kh // 2, kw // 2), act=2, x2=xb), torch.relu(ref), "gconv2d x2", atol=tol, rtol=0)
+    # scaling the input by a power of two scales every bf16 piece and every partial sum exactly: bitwise equivariance
+    ws0, z64 = hip.pack_conv_weight_split(wt.cuda(), None)
+    o1, o2 = torch.empty_like(out), torch.empty_like(out)
+    hip._conv_split(x.cuda(), (ws0, z64), cout, kh, kw, 0, None, False, o1)
+    hip._conv_split((x * 1024.0).cuda(), (ws0, z64), cout, kh, kw, 0, None, False, o2)
+    assert torch.equal(o1 * 1024.0, o2), "split conv is not exactly equivariant under power-of-two scaling"
     # the exact-f32 kernel on the same operands: the two agree to float32 rounding level
     wp, bp = hip.pack_gconv_weight(wt.cuda(), b.cuda())
     hip.set_conv_mode("exact")
