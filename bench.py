@@ -160,6 +160,8 @@ def main():
                 traffic = tj.get("moments_kernel_hbm_bytes_per_launch")
         roof = {"bound": "hbm", "kernel": dom, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": ach / HBM_PEAK, "traffic": traffic,
+                "limiter": "VALU issue rate, not HBM: the float64-exact sRGB<->Lab arithmetic needs ~119 (stats) / ~205 "
+                           "(apply) VALU instructions per pixel at >= 4 cycles each (DESIGN.md 4.1); HBM traffic == algorithmic bytes",
                 "algorithmic_bytes_per_launch": kern[dom]["bytes"], "avg_launch_s": kern[dom]["t"],
                 "kernels": {k: {"GB/s": v["bytes"] / v["t"] / 1e9, "avg_launch_us": v["t"] * 1e6,
                                 "algorithmic_bytes_per_launch": v["bytes"]} for k, v in kern.items()},
