@@ -1,0 +1,190 @@
+// ct_color_lut.h -- table-driven sRGB <-> Lab arithmetic for float32 images on gfx950.
+//
+// Same functions as ct_color.h (scikit-image 0.18.3 rgb2lab / lab2rgb as called at methods/linear.py:25,26,40), but every
+// power function is ONE look-up in an LDS-resident table plus a short polynomial instead of a v_log_f32 / v_exp_f32 seed
+// and a float64 Newton correction.  Why (measured, tools/ubench/lut_rates.hip): on this chip a float64 VALU op costs
+// ~2.1 ns per wave and SIMD, a float32 op ~1.2 ns, a transcendental ~3.6 ns, a float64 select ~8 ns, while a random
+// 8-byte / 16-byte LDS look-up costs the CU 7.3 / 11.9 cycles per wave (bank conflicts included).  The exact path spends
+// ~74 cycles per gamma expansion and ~46 per cube root; the table path ~24 and ~30.
+//
+// Accuracy (tools/gen_lab_tables.py verifies each table against 40-digit arithmetic): linear values <= 1.6e-10 absolute,
+// cube roots <= 1e-9 relative, gamma compression <= 6e-8 absolute (the float32 output rounding is 3e-8).  In Lab that is
+// ~5e-7 before the float32 output rounding -- two orders below the 1e-4 gate; the statistics agree with the float64
+// path to ~1e-7.  Inputs outside [0,1], NaNs and non-finite statistics never enter this path: the kernels test for them
+// (wave-uniform) and fall back to ct_color.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ct_color.h"
+#include "ct_lab_tables.h"
+
+namespace ct {
+namespace lut {
+
+// LDS image of the tables (byte offsets)
+constexpr int kLdsA = 0;
+constexpr int kLdsB = kLdsA + kAEntries * 16;
+constexpr int kLdsC = kLdsB + kBEntries * 8;
+constexpr int kCFirst = 6 << kCBits;                        // first entry of table C that is ever read (2^-9)
+constexpr int kLdsBytesFwd = kLdsC;                         // forward transform only (A, B)
+constexpr int kLdsBytesAll = kLdsC + (kCEntries - kCFirst) * 16;
+static_assert(kLdsB % 16 == 0 && kLdsC % 16 == 0, "16-byte aligned tables");
+static_assert(kLdsC >= kCFirst * 16, "table C is addressed with a negative bias");
+
+// cooperative copy global (L2-resident, 37 KB) -> LDS, 16 bytes per thread and step; caller synchronises
+template <int THREADS, bool WITH_C>
+__device__ __forceinline__ void load_tables(unsigned char *lds) {
+    const uint4 *a = reinterpret_cast<const uint4 *>(kTableA);
+    const uint4 *b = reinterpret_cast<const uint4 *>(kTableB);
+    uint4 *la = reinterpret_cast<uint4 *>(lds + kLdsA), *lb = reinterpret_cast<uint4 *>(lds + kLdsB);
+    for (int i = threadIdx.x; i < kAEntries; i += THREADS) la[i] = a[i];
+    for (int i = threadIdx.x; i < kBEntries / 2; i += THREADS) lb[i] = b[i];
+    if (WITH_C) {
+        const uint4 *c = reinterpret_cast<const uint4 *>(kTableC) + kCFirst;
+        uint4 *lc = reinterpret_cast<uint4 *>(lds + kLdsC);
+        for (int i = threadIdx.x; i < kCEntries - kCFirst; i += THREADS) lc[i] = c[i];
+    }
+}
+
+// float32 image of tables A and B for the statistics sweep (same LDS layout and size): A -> {float(a0), a1, a2, 0},
+// B -> {c = v_i^(1/3), 1 / v_i} at the same nodes v_i (the top 8 mantissa bits of a float and of a double coincide)
+template <int THREADS>
+__device__ __forceinline__ void load_tables_f32(unsigned char *lds) {
+    const uint4 *a = reinterpret_cast<const uint4 *>(kTableA);
+    float4 *la = reinterpret_cast<float4 *>(lds + kLdsA);
+    for (int i = threadIdx.x; i < kAEntries; i += THREADS) {
+        const uint4 e = a[i];
+        la[i] = make_float4((float)__hiloint2double((int)e.y, (int)e.x), __uint_as_float(e.z), __uint_as_float(e.w), 0.0f);
+    }
+    float2 *lb = reinterpret_cast<float2 *>(lds + kLdsB);
+    for (int i = threadIdx.x; i < kBEntries; i += THREADS) {
+        const double r = kTableB[i];
+        const double v = __hiloint2double((int)((uint32_t)(1016 + (i >> kBBits)) << 20 | (uint32_t)(i & ((1 << kBBits) - 1)) << (20 - kBBits)), 0);
+        const double r2 = r * r;
+        lb[i] = make_float2((float)(v * r2), (float)(r2 * r));
+    }
+}
+
+// float32 bit pattern test: every value of a tile in [0,1] <=> max of the patterns (unsigned) <= bits(1.0f)
+// (negative numbers, -0, NaN and inf all have larger patterns)
+constexpr uint32_t kOneBits = 0x3f800000u;
+
+// ---- float64-grade pieces (apply sweep) ---------------------------------------------------------------------------
+// sRGB gamma expansion of a float32 in [0,1] (c slightly outside extrapolates the end segments)
+__device__ __forceinline__ double expand(const unsigned char *lds, float c) {
+    const float y = fmaf(c, kAScale, kMagic);                                   // MAGIC + round(c * S)
+    const uint32_t off = (__float_as_uint(y) << 4) - (kMagicBits << 4);         // 16 * index
+    const float d = fmaf(y - kMagic, kANegInv, c);                              // c - index / S
+    const uint4 e = *reinterpret_cast<const uint4 *>(lds + kLdsA + off);        // one ds_read_b128: {a0 (double), a1, a2}
+    const double a0 = __hiloint2double((int)e.y, (int)e.x);
+    return a0 + (double)(d * fmaf(d, __uint_as_float(e.w), __uint_as_float(e.z)));
+}
+
+// cube root of a float64 in [2^-7, 2): r = v^(-1/3) at the nearest of 256 nodes per octave, then one quadratic in v r^3
+__device__ __forceinline__ double cbrt_lut(const unsigned char *lds, double v) {
+    const uint32_t hi = (uint32_t)__double2hiint(v);
+    const uint32_t off = ((hi + (1u << (19 - kBBits))) >> (17 - kBBits)) & (((8u << kBBits) - 1u) << 3);
+    const double r = *reinterpret_cast<const double *>(lds + kLdsB + off);
+    const double t = v * r, b = t * r, e = b * r;
+    return b * fma(fma(kBQ2, e, kBQ1), e, kBQ0);
+}
+
+constexpr int32_t kToeHiFwd = 0x3f822318;    // high word of 0.008856: hi(v) > this  =>  v > 0.008856
+constexpr int32_t kToeHiInv = 0x3fca7b96;    // high word of 0.2068966
+
+// one pixel (float32, all three in [0,1]) -> (fx, fy, fz).  The linear toe of Lab's f() is patched behind ONE integer
+// test on the high words (positive doubles order like their bit patterns): the float64 selects run only when some
+// lane of the wave needs them.
+__device__ __forceinline__ void rgb_to_f(const unsigned char *lds, float r, float g, float b, double &fx, double &fy, double &fz) {
+    const double lr = expand(lds, r), lg = expand(lds, g), lb = expand(lds, b);
+    const double x = fma(lb, CT_M02, fma(lg, CT_M01, lr * CT_M00));
+    const double y = fma(lb, CT_M12, fma(lg, CT_M11, lr * CT_M10));
+    const double z = fma(lb, CT_M22, fma(lg, CT_M21, lr * CT_M20));
+    fx = cbrt_lut(lds, x);
+    fy = cbrt_lut(lds, y);
+    fz = cbrt_lut(lds, z);
+    const int32_t m = min(min(__double2hiint(x), __double2hiint(y)), __double2hiint(z));
+    if (__builtin_amdgcn_ballot_w64(m <= kToeHiFwd)) {
+        asm volatile("; lab toe" : "+v"(fx));
+        fx = (x > 0.008856) ? fx : fma(7.787, x, 16.0 / 116.0);
+        fy = (y > 0.008856) ? fy : fma(7.787, y, 16.0 / 116.0);
+        fz = (z > 0.008856) ? fz : fma(7.787, z, 16.0 / 116.0);
+    }
+}
+
+// sRGB gamma compression + clip to [0,1], float32 result (u: linear value, any finite double)
+__device__ __forceinline__ float compress_clip(const unsigned char *lds, double u) {
+    const float uf = __builtin_amdgcn_fmed3f((float)u, 0.0f, 1.0f);
+    const uint32_t bits = __float_as_uint(uf) + (1u << (22 - kCBits));
+    const uint32_t off = (bits >> (19 - kCBits)) & (((16u << kCBits) - 1u) << 4);
+    const float d = uf - __uint_as_float(bits & ~((1u << (23 - kCBits)) - 1u));
+    const float4 e = *reinterpret_cast<const float4 *>(lds + (kLdsC - kCFirst * 16) + off);   // {a0, a1, a2, a3}
+    const float p = fmaf(d, fmaf(d, fmaf(d, e.w, e.z), e.y), e.x);
+    return (uf <= 0.0031308f) ? 12.92f * uf : p;
+}
+
+// one pixel: (fx, fy, fz), all finite -> clipped float32 sRGB
+__device__ __forceinline__ void f_to_rgb_clip(const unsigned char *lds, double fx, double fy, double fz, float &r, float &g, float &b) {
+    double x = (fx * fx) * fx, y = (fy * fy) * fy, z = (fz * fz) * fz;
+    const int32_t m = min(min(__double2hiint(fx), __double2hiint(fy)), __double2hiint(fz));   // negative doubles: negative ints
+    if (__builtin_amdgcn_ballot_w64(m <= kToeHiInv)) {
+        asm volatile("; lab toe" : "+v"(x));
+        fz = (fz < 0.0) ? 0.0 : fz;            // lab2xyz: z < 0 -> 0
+        z = (fz * fz) * fz;
+        x = (fx > 0.2068966) ? x : fma(fx, 1.0 / 7.787, -(16.0 / 116.0) / 7.787);
+        y = (fy > 0.2068966) ? y : fma(fy, 1.0 / 7.787, -(16.0 / 116.0) / 7.787);
+        z = (fz > 0.2068966) ? z : fma(fz, 1.0 / 7.787, -(16.0 / 116.0) / 7.787);
+    }
+    r = compress_clip(lds, fma(z, CT_I02, fma(y, CT_I01, x * CT_I00)));
+    g = compress_clip(lds, fma(z, CT_I12, fma(y, CT_I11, x * CT_I10)));
+    b = compress_clip(lds, fma(z, CT_I22, fma(y, CT_I21, x * CT_I20)));
+}
+
+// ---- float32 pieces (statistics sweep; tables from load_tables_f32) --------------------------------------------------
+// Means and variances over ~2 M pixels only need UNBIASED per-pixel values: correctly rounded float32 arithmetic
+// (errors ~6e-8, symmetric) changes the Lab statistics by ~1e-7, far below the float32 rounding of any output pixel,
+// at half the VALU cost of float64.  (The apply sweep keeps float64: there a = 500 (fx - fy) must be right per pixel.)
+__device__ __forceinline__ float expand32(const unsigned char *lds, float c) {
+    const float y = fmaf(c, kAScale, kMagic);
+    const uint32_t off = (__float_as_uint(y) << 4) - (kMagicBits << 4);
+    const float d = fmaf(y - kMagic, kANegInv, c);
+    float4 e = *reinterpret_cast<const float4 *>(lds + kLdsA + off);            // {a0, a1, a2, -}
+    asm volatile("" : "+v"(e.w));       // keeps the access one ds_read_b128 (the compiler narrows it to the slower b96)
+    return fmaf(d, fmaf(d, e.z, e.y), e.x);
+}
+
+// cube root of a float32 in [2^-7, 2): c_i (1 + p), p = (1 + delta)^(1/3) - 1 to second order, delta = (v - v_i) / v_i <= 2^-9
+__device__ __forceinline__ float cbrt32(const unsigned char *lds, float v) {
+    const uint32_t bits = __float_as_uint(v) + (1u << (22 - kBBits));
+    const uint32_t off = (bits >> (20 - kBBits)) & (((8u << kBBits) - 1u) << 3);
+    const float d = v - __uint_as_float(bits & ~((1u << (23 - kBBits)) - 1u));  // exact
+    const float2 e = *reinterpret_cast<const float2 *>(lds + kLdsB + off);      // {c_i, 1 / v_i}
+    const float dl = d * e.y;
+    return fmaf(e.x, dl * fmaf(dl, -1.0f / 9.0f, 1.0f / 3.0f), e.x);
+}
+
+// matrix row in float32 with two-piece constants: a constant rounded to float32 is off by up to 3e-8 relative for EVERY
+// pixel -- a bias, not noise (measured: 2.5e-6 in the mean of a*) -- so each weight is hi + lo and the lo terms go first
+#define CT_ROW32(lr, lg, lb, A, B, C)                                                                                                  \
+    fmaf(lb, (float)(C), fmaf(lg, (float)(B), fmaf(lr, (float)(A),                                                                     \
+         fmaf(lb, (float)((C) - (double)(float)(C)), fmaf(lg, (float)((B) - (double)(float)(B)), lr * (float)((A) - (double)(float)(A)))))))
+
+__device__ __forceinline__ void rgb_to_f32(const unsigned char *lds, float r, float g, float b, float &fx, float &fy, float &fz) {
+    const float lr = expand32(lds, r), lg = expand32(lds, g), lb = expand32(lds, b);
+    const float x = CT_ROW32(lr, lg, lb, CT_M00, CT_M01, CT_M02);
+    const float y = CT_ROW32(lr, lg, lb, CT_M10, CT_M11, CT_M12);
+    const float z = CT_ROW32(lr, lg, lb, CT_M20, CT_M21, CT_M22);
+    fx = cbrt32(lds, x);
+    fy = cbrt32(lds, y);
+    fz = cbrt32(lds, z);
+    if (__builtin_amdgcn_ballot_w64(fminf(fminf(x, y), z) <= 0.008856f)) {
+        asm volatile("; lab toe" : "+v"(fx));
+        fx = (x > 0.008856f) ? fx : fmaf(7.787f, x, (float)(16.0 / 116.0));
+        fy = (y > 0.008856f) ? fy : fmaf(7.787f, y, (float)(16.0 / 116.0));
+        fz = (z > 0.008856f) ? fz : fmaf(7.787f, z, (float)(16.0 / 116.0));
+    }
+}
+
+}  // namespace lut
+}  // namespace ct

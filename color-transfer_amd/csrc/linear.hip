@@ -15,6 +15,7 @@
 // S1 = sum(x-K), S2 = sum((x-K)(x-K)^T) are plainly additive across lanes/workgroups, and
 // mean = K + S1/n, M2 = S2 - S1 S1^T / n is stable in float64 even for near-constant images.
 #include "ct_color.h"
+#include "ct_color_lut.h"
 #include "ct_common.h"
 
 namespace ct {
@@ -256,6 +257,254 @@ __global__ __launch_bounds__(kBlock) CT_WPE void reinhard_apply_kernel(const T *
 }
 
 // -------------------------------------------------------------------------------------------
+// Table-driven variants of A1 / A2 for float32 images (ct_color_lut.h): the power functions are LDS look-ups.
+//
+// Work layout: a wave owns TILES of 256 consecutive pixels; lane l holds pixels l, l+64, l+128, l+192 of the tile, each
+// fetched / stored with ONE 12-byte access (global_load/store_dwordx3): consecutive lanes touch consecutive bytes, so
+// every wave instruction covers 768 contiguous bytes whatever the alignment of the image (measured,
+// tools/ubench/stream_patterns.hip: a copy runs at 5.5 TB/s this way against 4.6 TB/s with three 16-byte accesses per lane
+// at a 48-byte lane stride).  512-thread workgroups share one 32 KB (statistics) / 37 KB (apply) table image and are
+// persistent: one round of resident workgroups sweeps all tiles.  A tile whose wave holds any value outside [0,1] (or a
+// NaN) is computed with the exact float64 code of ct_color.h, pixel by pixel.
+// -------------------------------------------------------------------------------------------
+constexpr int kLutBlock = 512;
+constexpr int kLutWaves = kLutBlock / kWave;
+constexpr int kTilePixels = 4 * kWave;
+// minimum waves per SIMD the table kernels are compiled for (register budget): tuning builds override
+#ifndef CT_LUT_WPE_STATS
+#define CT_LUT_WPE_STATS 4
+#endif
+#ifndef CT_LUT_WPE_APPLY
+#define CT_LUT_WPE_APPLY 4
+#endif
+#ifndef CT_LUT_PREFETCH    // 1: register double buffer of the next tile; 0: rely on occupancy
+#define CT_LUT_PREFETCH 1
+#endif
+
+typedef float float3v __attribute__((ext_vector_type(3)));
+typedef float3v float3u __attribute__((aligned(4)));
+
+__device__ __forceinline__ void load_tile(const float *tile, int lane, float (&e)[12]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float3v a = *reinterpret_cast<const float3u *>(tile + (j * kWave + lane) * 3);
+        e[3 * j] = a.x; e[3 * j + 1] = a.y; e[3 * j + 2] = a.z;
+    }
+}
+__device__ __forceinline__ void store_tile(float *tile, int lane, const float (&e)[12]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<float3u *>(tile + (j * kWave + lane) * 3) = float3v{e[3 * j], e[3 * j + 1], e[3 * j + 2]};
+}
+
+__device__ __forceinline__ uint32_t max_bits12(const float (&e)[12]) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) m = max(m, __float_as_uint(e[i]));
+    return m;
+}
+
+// rotate the four pixels of a lane by one: the exact fallback stays a rolled loop over "pixel 0" (one copy of the code,
+// few registers) without indexing the register array dynamically; four rotations restore the order
+__device__ __forceinline__ void rotate_pixels(float (&e)[12]) {
+    const float a = e[0], b = e[1], c = e[2];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) e[i] = e[i + 3];
+    e[9] = a; e[10] = b; e[11] = c;
+}
+__device__ __forceinline__ double uniform_f64(double v) {     // wave-uniform double -> SGPR pair
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+template <int NV, int NW>
+__device__ __forceinline__ void block_sum_n(double (&v)[NV], double *lds /* [NW][NV] */) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] += __shfl_down(v[i], off, kWave);
+    }
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wid = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) lds[wid * NV + i] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            double a = lds[i];
+            for (int w = 1; w < NW; ++w) a += lds[w * NV + i];   // wave order: fixed
+            v[i] = a;
+        }
+    }
+}
+
+// A1, float32 arithmetic on the table path (see ct_color_lut.h: statistics only need unbiased per-pixel values): per lane
+// float32 shifted sums over its ~40 pixels, converted once to float64 for the fixed-shape reduction tree.  The exact
+// fallback (out-of-range tiles, the ragged last tile) accumulates in float64 beside it.
+__global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_STATS) void lab_moments_lut_kernel(const float *__restrict__ base0,
+                                                                                      const float *__restrict__ base1, int n_first,
+                                                                                      int64_t n_pixels, double *__restrict__ partials,
+                                                                                      double *__restrict__ pivots) {
+    __shared__ __attribute__((aligned(16))) unsigned char tab[lut::kLdsBytesFwd];
+    __shared__ double red[kLutWaves * 6];
+    __shared__ double piv[3];
+    const int img = blockIdx.y;
+    const float *p = (img < n_first) ? base0 + (size_t)img * n_pixels * 3 : base1 + (size_t)(img - n_first) * n_pixels * 3;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t n_full = n_pixels / kTilePixels;                   // full tiles; the ragged rest is swept by workgroup 0
+    const int64_t stride = (int64_t)gridDim.x * kLutWaves;
+    int64_t t = (int64_t)blockIdx.x * kLutWaves + (threadIdx.x >> 6);
+    float cur[12];
+#if CT_LUT_PREFETCH
+    float nxt[12];
+#endif
+    if (t < n_full) load_tile(p + t * (kTilePixels * 3), lane, cur);          // in flight while the tables are built
+    lut::load_tables_f32<kLutBlock>(tab);
+    if (threadIdx.x == 0) {                                          // pivot: pixel 0 of the image, exact arithmetic
+        double k0 = 0.0, k1 = 0.0, k2 = 0.0;
+        if (n_pixels > 0) to_space<true>((double)p[0], (double)p[1], (double)p[2], k0, k1, k2);
+        piv[0] = k0; piv[1] = k1; piv[2] = k2;
+    }
+    __syncthreads();
+    const double k[3] = {uniform_f64(piv[0]), uniform_f64(piv[1]), uniform_f64(piv[2])};
+    // the pivot both accumulators share, on a 2^-10 grid: (value on the 2^-26 grid of a float32 difference) - (pivot with
+    // finer bits) would round the SAME way for every pixel -- a bias of half an ulp (measured: 4e-9, i.e. 2e-6 in mean a*)
+    const float kf[3] = {rintf((float)k[0] * 1024.0f) * (1.0f / 1024.0f), rintf((float)k[1] * 1024.0f) * (1.0f / 1024.0f),
+                         rintf((float)k[2] * 1024.0f) * (1.0f / 1024.0f)};
+    const double kd[3] = {(double)kf[0], (double)kf[1], (double)kf[2]};
+    double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    float sf[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (; t < n_full; t += stride) {
+#if CT_LUT_PREFETCH
+        if (t + stride < n_full) load_tile(p + (t + stride) * (kTilePixels * 3), lane, nxt);
+#endif
+        if (__builtin_amdgcn_ballot_w64(max_bits12(cur) > lut::kOneBits)) {
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+                double x, y, z;
+                to_space<true>((double)cur[0], (double)cur[1], (double)cur[2], x, y, z);
+                accumulate<true>(s, kd, x, y, z);
+                rotate_pixels(cur);
+                asm volatile("" : "+v"(cur[0]));     // keep the loop rolled
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float fx, fy, fz;
+                lut::rgb_to_f32(tab, cur[3 * q], cur[3 * q + 1], cur[3 * q + 2], fx, fy, fz);
+                const float dx = fy - kf[0], dy = (fx - fy) - kf[1], dz = (fy - fz) - kf[2];
+                sf[0] += dx; sf[1] += dy; sf[2] += dz;
+                sf[3] = fmaf(dx, dx, sf[3]); sf[4] = fmaf(dy, dy, sf[4]); sf[5] = fmaf(dz, dz, sf[5]);
+            }
+        }
+#if CT_LUT_PREFETCH
+#pragma unroll
+        for (int i = 0; i < 12; ++i) cur[i] = nxt[i];
+#else
+        if (t + stride < n_full) load_tile(p + (t + stride) * (kTilePixels * 3), lane, cur);
+#endif
+    }
+    if (blockIdx.x == 0) {                                           // ragged tail (n_pixels % 256), exact arithmetic
+        const int64_t px = n_full * kTilePixels + threadIdx.x;
+        if (threadIdx.x < kTilePixels && px < n_pixels) {
+            double x, y, z;
+            to_space<true>((double)p[px * 3], (double)p[px * 3 + 1], (double)p[px * 3 + 2], x, y, z);
+            accumulate<true>(s, kd, x, y, z);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s[i] += (double)sf[i];
+    block_sum_n<6, kLutWaves>(s, red);
+    if (threadIdx.x == 0) {
+        double *dst = partials + ((size_t)img * kMaxBlocksPerImage + blockIdx.x) * kPartialStride;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dst[i] = s[i];
+        if (blockIdx.x == 0) {
+            pivots[img * kPivotStride + 0] = kd[0];
+            pivots[img * kPivotStride + 1] = kd[1];
+            pivots[img * kPivotStride + 2] = kd[2];
+        }
+    }
+}
+
+// A2 on the table path, float64-grade (a* = 500 (fx - fy) must be right per pixel).
+template <bool OUT_LAB>
+__global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_APPLY) void reinhard_apply_lut_kernel(const float *__restrict__ target,
+                                                                                         const double *__restrict__ stats_t,
+                                                                                         const double *__restrict__ stats_r,
+                                                                                         float *__restrict__ out, int64_t n_pixels) {
+    __shared__ __attribute__((aligned(16))) unsigned char tab[OUT_LAB ? lut::kLdsBytesFwd : lut::kLdsBytesAll];
+    const int img = blockIdx.y;
+    const float *p = target + (size_t)img * n_pixels * 3;
+    float *o = out + (size_t)img * n_pixels * 3;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t n_full = n_pixels / kTilePixels;
+    const int64_t stride = (int64_t)gridDim.x * kLutWaves;
+    int64_t t = (int64_t)blockIdx.x * kLutWaves + (threadIdx.x >> 6);
+    float cur[12];
+#if CT_LUT_PREFETCH
+    float nxt[12];
+#endif
+    if (t < n_full) load_tile(p + t * (kTilePixels * 3), lane, cur);
+    lut::load_tables<kLutBlock, !OUT_LAB>(tab);
+    ReinhardCoef c = reinhard_coef(stats_t + (size_t)img * CT_LAB_STATS_STRIDE, stats_r + (size_t)img * CT_LAB_STATS_STRIDE);
+    c.sL = uniform_f64(c.sL); c.sa = uniform_f64(c.sa); c.sb = uniform_f64(c.sb);
+    c.cy = uniform_f64(c.cy); c.ca = uniform_f64(c.ca); c.cb = uniform_f64(c.cb);
+    // the table path needs finite, moderate coefficients (then every intermediate is finite); anything else -- a
+    // constant target gives inf / nan like the reference -- goes through the exact code
+    const double cmax = fmax(fmax(fmax(fabs(c.sL), fabs(c.sa)), fmax(fabs(c.sb), fabs(c.cy))), fmax(fabs(c.ca), fabs(c.cb)));
+    const bool coef_bad = !(cmax < 1e6);
+    __syncthreads();
+    for (; t < n_full; t += stride) {
+#if CT_LUT_PREFETCH
+        if (t + stride < n_full) load_tile(p + (t + stride) * (kTilePixels * 3), lane, nxt);
+#endif
+        float w[12];
+        if (coef_bad || __builtin_amdgcn_ballot_w64(max_bits12(cur) > lut::kOneBits)) {
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+                rotate_pixels(w);                      // the result of pixel q lands in slot 3 and ends in slot q
+                reinhard_pixel<float, OUT_LAB>(c, (double)cur[0], (double)cur[1], (double)cur[2], w[9], w[10], w[11]);
+                rotate_pixels(cur);
+                asm volatile("" : "+v"(cur[0]));       // keep the loop rolled
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double fx, fy, fz;
+                lut::rgb_to_f(tab, cur[3 * q], cur[3 * q + 1], cur[3 * q + 2], fx, fy, fz);
+                const double gy = fma(c.sL, fy, c.cy);
+                const double gx = gy + fma(c.sa, fx - fy, c.ca);
+                const double gz = gy - fma(c.sb, fy - fz, c.cb);
+                if (OUT_LAB) {
+                    double L, A, B;
+                    f_to_lab(gx, gy, gz, L, A, B);
+                    w[3 * q] = (float)L; w[3 * q + 1] = (float)A; w[3 * q + 2] = (float)B;
+                } else {
+                    lut::f_to_rgb_clip(tab, gx, gy, gz, w[3 * q], w[3 * q + 1], w[3 * q + 2]);
+                }
+            }
+        }
+        store_tile(o + t * (kTilePixels * 3), lane, w);
+#if CT_LUT_PREFETCH
+#pragma unroll
+        for (int i = 0; i < 12; ++i) cur[i] = nxt[i];
+#else
+        if (t + stride < n_full) load_tile(p + (t + stride) * (kTilePixels * 3), lane, cur);
+#endif
+    }
+    if (blockIdx.x == 0) {                                           // ragged tail (n_pixels % 256), exact arithmetic
+        const int64_t px = n_full * kTilePixels + threadIdx.x;
+        if (threadIdx.x < kTilePixels && px < n_pixels) {
+            float a, b, d;
+            reinhard_pixel<float, OUT_LAB>(c, (double)p[px * 3], (double)p[px * 3 + 1], (double)p[px * 3 + 2], a, b, d);
+            o[px * 3] = a; o[px * 3 + 1] = b; o[px * 3 + 2] = d;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
 // A5: out = (x - mu_t) @ A + mu_r, float64 arithmetic, unclipped
 // -------------------------------------------------------------------------------------------
 template <typename TI, typename TO>
@@ -481,14 +730,53 @@ static int check_ws(const void *ws, size_t ws_bytes, int n_images) {
 // set with ct_profile_events(); NULL = off.  Recorded on the launch stream, so they time exactly one kernel.
 static hipEvent_t g_prof_evt[4] = {nullptr, nullptr, nullptr, nullptr};
 
+// Lab arithmetic of the float32 entries: 0 = table-driven (ct_color_lut.h, default), 1 = exact float64 (ct_color.h).
+// float64 images always take the exact path.  Process-wide; set before launching (ct_set_lab_mode / env CT_HIP_LAB).
+static int g_lab_mode = [] { const char *e = getenv("CT_HIP_LAB"); return (e && e[0] == 'e') ? 1 : 0; }();
+
+// Workgroups of a table kernel: ONE round of persistent workgroups -- as many as are resident at once (occupancy query,
+// cached per kernel), each sweeping enough chunks to amortise its 32-37 KB table copy.  CT_HIP_LUT_BLOCKS overrides the
+// total (tuning).
+template <typename K>
+static int resident_blocks(K kernel) {
+    int dev = 0, per_cu = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kLutBlock, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    (void)hipGetLastError();
+    return per_cu * cus;
+}
+static int lut_blocks_per_image(int resident, int64_t n_tiles, int n_images) {
+    static int forced = [] { const char *e = getenv("CT_HIP_LUT_BLOCKS"); return e ? atoi(e) : 0; }();
+    const int total = forced > 0 ? forced : resident;
+    int64_t want = (n_tiles + kLutWaves - 1) / kLutWaves;
+    int64_t cap = total / (n_images > 0 ? n_images : 1);
+    if (cap < 4) cap = 4;
+    if (cap > kMaxBlocksPerImage) cap = kMaxBlocksPerImage;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
 template <typename T, bool LAB>
 static int launch_moments(const T *base0, const T *base1, int n_first, int n_images, int64_t n_pixels,
                           const WsLayout &l, double *stats, hipStream_t s) {
     if (n_images == 0) return CT_OK;
-    const int G = blocks_per_image(n_pixels >> 2, n_images);
+    constexpr bool kLut = LAB && sizeof(T) == 4;
+    const bool use_lut = kLut && g_lab_mode == 0;
+    int G = blocks_per_image(n_pixels >> 2, n_images);
+    if constexpr (kLut) {
+        static const int resident = resident_blocks(lab_moments_lut_kernel);
+        if (use_lut) G = lut_blocks_per_image(resident, n_pixels / kTilePixels, n_images);
+    }
     if (LAB && g_prof_evt[0]) (void)hipEventRecord(g_prof_evt[0], s);
-    hipLaunchKernelGGL((moments_kernel<T, LAB>), dim3(G, n_images), dim3(kBlock), 0, s, base0, base1, n_first,
-                       n_pixels, l.partials, l.pivots);
+    if constexpr (kLut) {
+        if (use_lut)
+            hipLaunchKernelGGL(lab_moments_lut_kernel, dim3(G, n_images), dim3(kLutBlock), 0, s, base0, base1, n_first, n_pixels,
+                               l.partials, l.pivots);
+    }
+    if (!use_lut)
+        hipLaunchKernelGGL((moments_kernel<T, LAB>), dim3(G, n_images), dim3(kBlock), 0, s, base0, base1, n_first,
+                           n_pixels, l.partials, l.pivots);
     CT_CHECK_LAUNCH();
     if (LAB && g_prof_evt[1]) (void)hipEventRecord(g_prof_evt[1], s);
     hipLaunchKernelGGL((moments_finalize_kernel<LAB>), dim3(n_images), dim3(kBlock), 0, s, l.partials, l.pivots, G,
@@ -501,10 +789,22 @@ template <typename T, bool OUT_LAB>
 static int launch_reinhard_apply(const T *target, const double *st, const double *sr, T *out, int64_t n_pixels,
                                  int batch, hipStream_t s) {
     if (batch == 0 || n_pixels == 0) return CT_OK;
-    const int G = blocks_per_image(n_pixels >> 2, batch);
+    constexpr bool kLut = sizeof(T) == 4;
+    const bool use_lut = kLut && g_lab_mode == 0;
+    int G = blocks_per_image(n_pixels >> 2, batch);
+    if constexpr (kLut) {
+        static const int resident = resident_blocks(reinhard_apply_lut_kernel<OUT_LAB>);
+        if (use_lut) G = lut_blocks_per_image(resident, n_pixels / kTilePixels, batch);
+    }
     if (g_prof_evt[2]) (void)hipEventRecord(g_prof_evt[2], s);
-    hipLaunchKernelGGL((reinhard_apply_kernel<T, OUT_LAB>), dim3(G, batch), dim3(kBlock), 0, s, target, st, sr, out,
-                       n_pixels);
+    if constexpr (kLut) {
+        if (use_lut)
+            hipLaunchKernelGGL((reinhard_apply_lut_kernel<OUT_LAB>), dim3(G, batch), dim3(kLutBlock), 0, s, target, st, sr, out,
+                               n_pixels);
+    }
+    if (!use_lut)
+        hipLaunchKernelGGL((reinhard_apply_kernel<T, OUT_LAB>), dim3(G, batch), dim3(kBlock), 0, s, target, st, sr, out,
+                           n_pixels);
     CT_CHECK_LAUNCH();
     if (g_prof_evt[3]) (void)hipEventRecord(g_prof_evt[3], s);
     return CT_OK;
@@ -633,6 +933,13 @@ static int mk_impl(const T *target, const T *reference, TO *out, int64_t n_pixel
 extern "C" {
 
 int ct_abi_version(void) { return CT_ABI_VERSION; }
+
+int ct_set_lab_mode(int mode) {
+    if (mode != CT_LAB_TABLE && mode != CT_LAB_EXACT) return CT_E_BADARG;
+    ct::g_lab_mode = mode;
+    return CT_OK;
+}
+int ct_get_lab_mode(void) { return ct::g_lab_mode; }
 
 void ct_profile_events(void *moments_start, void *moments_stop, void *apply_start, void *apply_stop) {
     ct::g_prof_evt[0] = (hipEvent_t)moments_start;

@@ -31,6 +31,8 @@ SIGNATURES = {
     "ct_abi_version": (_c_int, []),
     "ct_error_string": (ctypes.c_char_p, [_c_int]),
     "ct_profile_events": (None, [_c_p, _c_p, _c_p, _c_p]),
+    "ct_set_lab_mode": (_c_int, [_c_int]),
+    "ct_get_lab_mode": (_c_int, []),
     "ct_workspace_bytes": (_c_sz, [_c_int, _c_i64, _c_int]),
     "ct_lab_stats_f32": (_c_int, [_c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
     "ct_lab_stats_f64": (_c_int, [_c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
@@ -97,6 +99,14 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _check_device(t):
+    """Kernels launch on the CURRENT device's stream: a tensor that lives elsewhere would be touched from the wrong
+    context.  One process drives one GPU here, so this is an error, not a device switch."""
+    if t.device.index is not None and t.device.index != torch.cuda.current_device():
+        raise CtHipError("tensor on %s but the current device is cuda:%d; call torch.cuda.set_device(%d) first"
+                         % (t.device, torch.cuda.current_device(), t.device.index))
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
@@ -107,6 +117,7 @@ def _require_cuda(*tensors):
             raise CtHipError("ct_hip needs device tensors (got %s); no CPU path exists" % t.device)
         if not t.is_contiguous():
             raise CtHipError("ct_hip needs contiguous HWC tensors")
+        _check_device(t)
 
 
 _ws_cache = {}
@@ -117,10 +128,11 @@ def workspace(kind, n_pixels, n_images, device, need=None):
     if need is None:
         need = lib().ct_workspace_bytes(kind, n_pixels, n_images)
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    buf = _ws_cache.get(key)
-    if buf is None or buf.numel() < need:
-        buf = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
-        _ws_cache[key] = buf
+    with _lock:
+        buf = _ws_cache.get(key)
+        if buf is None or buf.numel() < need:
+            buf = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
+            _ws_cache[key] = buf
     return buf
 
 
@@ -139,6 +151,22 @@ def _suffix(t):
     if t.dtype == torch.float64:
         return "f64"
     raise CtHipError("unsupported dtype %s (float32/float64 only)" % t.dtype)
+
+
+CT_LAB_TABLE, CT_LAB_EXACT = 0, 1
+
+
+def set_lab_mode(mode):
+    """Lab arithmetic of the float32 Reinhard entries: "table" (default; LDS look-up tables, Lab within ~5e-7 of the
+    float64 path) or "exact" (float64 with hardware seeds).  Process-wide (ct_set_lab_mode, include/ct_hip.h)."""
+    code = {"table": CT_LAB_TABLE, "exact": CT_LAB_EXACT}.get(mode)
+    if code is None:
+        raise ValueError("lab mode must be 'table' or 'exact', got %r" % (mode,))
+    check(lib().ct_set_lab_mode(code))
+
+
+def lab_mode():
+    return "exact" if lib().ct_get_lab_mode() == CT_LAB_EXACT else "table"
 
 
 def profile_events(events):

@@ -16,7 +16,7 @@
  *   - images are interleaved HWC, C = 3, contiguous: pixel p of image b starts at
  *     base + (b * n_pixels + p) * 3 elements;
  *   - return value: 0 = CT_OK, negative = CT_E_* argument error, positive = hipError_t;
- *   - all arithmetic is float64 internally; "_f32"/"_f64" name the I/O element type.
+ *   - arithmetic is float64 internally (see ct_set_lab_mode for the table-driven float32-image path); "_f32"/"_f64" name the I/O element type.
  */
 #ifndef CT_HIP_H
 #define CT_HIP_H
@@ -47,6 +47,17 @@ enum ct_workspace_kind {
 };
 
 int ct_abi_version(void);
+
+/* Lab arithmetic of the float32 entries (ct_lab_stats_f32, ct_reinhard_*_f32, ct_reinhard_lab_f32):
+ *   CT_LAB_TABLE (default)  the power functions of skimage's rgb2lab / lab2rgb (methods/linear.py:25,26,40) are LDS
+ *                           look-ups + short polynomials; Lab agrees with the float64 path to ~5e-7, statistics to ~1e-7;
+ *                           values outside [0,1], NaNs and degenerate statistics fall back to the exact code per wave;
+ *   CT_LAB_EXACT            float64 arithmetic with hardware seeds and one Newton correction (~1e-11 relative).
+ * float64 images always take the exact path.  Process-wide setting, not thread safe; env CT_HIP_LAB=exact presets it. */
+#define CT_LAB_TABLE 0
+#define CT_LAB_EXACT 1
+int ct_set_lab_mode(int mode);
+int ct_get_lab_mode(void);
 /* Measurement hook: four hipEvent_t (or NULL = off) that the library records on the launch stream immediately before /
  * after moments_kernel<T,true> and reinhard_apply_kernel of the following ct_lab_stats / ct_reinhard* calls, so that a
  * caller can time exactly those kernels with hipEventElapsedTime (bench.py `roofline`).  Not thread safe.              */
