@@ -22,53 +22,55 @@
 namespace ct {
 namespace lut {
 
-// LDS image of the tables (byte offsets)
+// LDS images of the tables (byte offsets).  float64-grade image (apply sweep): A {double a0; float a1, a2} 16 B,
+// B double r = v^(-1/3) 8 B, C {float a0..a3} 16 B.  float32 image (statistics sweep): A32 and B32, {c, s1, s2, node} 16 B.
 constexpr int kLdsA = 0;
 constexpr int kLdsB = kLdsA + kAEntries * 16;
 constexpr int kLdsC = kLdsB + kBEntries * 8;
 constexpr int kCFirst = 6 << kCBits;                        // first entry of table C that is ever read (2^-9)
 constexpr int kLdsBytesFwd = kLdsC;                         // forward transform only (A, B)
 constexpr int kLdsBytesAll = kLdsC + (kCEntries - kCFirst) * 16;
+constexpr int kLdsBytesF32 = kLdsB + kB32Entries * 16;
 static_assert(kLdsB % 16 == 0 && kLdsC % 16 == 0, "16-byte aligned tables");
 static_assert(kLdsC >= kCFirst * 16, "table C is addressed with a negative bias");
 
-// cooperative copy global (L2-resident, 37 KB) -> LDS, 16 bytes per thread and step; caller synchronises
+// cooperative copy global (L2-resident) -> LDS: every thread first issues all its 16-byte loads, then stores them (one
+// memory round trip for the whole image); caller synchronises
+template <int THREADS, int N>
+__device__ __forceinline__ void copy16(const uint4 *__restrict__ src, uint4 *dst) {
+    constexpr int STEPS = (N + THREADS - 1) / THREADS;
+    uint4 v[STEPS];
+#pragma unroll
+    for (int k = 0; k < STEPS; ++k)
+        if (k * THREADS + (int)threadIdx.x < N) v[k] = src[k * THREADS + threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < STEPS; ++k)
+        if (k * THREADS + (int)threadIdx.x < N) dst[k * THREADS + threadIdx.x] = v[k];
+}
 template <int THREADS, bool WITH_C>
 __device__ __forceinline__ void load_tables(unsigned char *lds) {
-    const uint4 *a = reinterpret_cast<const uint4 *>(kTableA);
-    const uint4 *b = reinterpret_cast<const uint4 *>(kTableB);
-    uint4 *la = reinterpret_cast<uint4 *>(lds + kLdsA), *lb = reinterpret_cast<uint4 *>(lds + kLdsB);
-    for (int i = threadIdx.x; i < kAEntries; i += THREADS) la[i] = a[i];
-    for (int i = threadIdx.x; i < kBEntries / 2; i += THREADS) lb[i] = b[i];
-    if (WITH_C) {
-        const uint4 *c = reinterpret_cast<const uint4 *>(kTableC) + kCFirst;
-        uint4 *lc = reinterpret_cast<uint4 *>(lds + kLdsC);
-        for (int i = threadIdx.x; i < kCEntries - kCFirst; i += THREADS) lc[i] = c[i];
-    }
+    copy16<THREADS, kAEntries>(reinterpret_cast<const uint4 *>(kTableA), reinterpret_cast<uint4 *>(lds + kLdsA));
+    copy16<THREADS, kBEntries / 2>(reinterpret_cast<const uint4 *>(kTableB), reinterpret_cast<uint4 *>(lds + kLdsB));
+    if (WITH_C)
+        copy16<THREADS, kCEntries - kCFirst>(reinterpret_cast<const uint4 *>(kTableC) + kCFirst, reinterpret_cast<uint4 *>(lds + kLdsC));
 }
-
-// float32 image of tables A and B for the statistics sweep (same LDS layout and size): A -> {float(a0), a1, a2, 0},
-// B -> {c = v_i^(1/3), 1 / v_i} at the same nodes v_i (the top 8 mantissa bits of a float and of a double coincide)
 template <int THREADS>
 __device__ __forceinline__ void load_tables_f32(unsigned char *lds) {
-    const uint4 *a = reinterpret_cast<const uint4 *>(kTableA);
-    float4 *la = reinterpret_cast<float4 *>(lds + kLdsA);
-    for (int i = threadIdx.x; i < kAEntries; i += THREADS) {
-        const uint4 e = a[i];
-        la[i] = make_float4((float)__hiloint2double((int)e.y, (int)e.x), __uint_as_float(e.z), __uint_as_float(e.w), 0.0f);
-    }
-    float2 *lb = reinterpret_cast<float2 *>(lds + kLdsB);
-    for (int i = threadIdx.x; i < kBEntries; i += THREADS) {
-        const double r = kTableB[i];
-        const double v = __hiloint2double((int)((uint32_t)(1016 + (i >> kBBits)) << 20 | (uint32_t)(i & ((1 << kBBits) - 1)) << (20 - kBBits)), 0);
-        const double r2 = r * r;
-        lb[i] = make_float2((float)(v * r2), (float)(r2 * r));
-    }
+    copy16<THREADS, kAEntries>(reinterpret_cast<const uint4 *>(kTableA32), reinterpret_cast<uint4 *>(lds + kLdsA));
+    copy16<THREADS, kB32Entries>(reinterpret_cast<const uint4 *>(kTableB32), reinterpret_cast<uint4 *>(lds + kLdsB));
 }
 
 // float32 bit pattern test: every value of a tile in [0,1] <=> max of the patterns (unsigned) <= bits(1.0f)
 // (negative numbers, -0, NaN and inf all have larger patterns)
 constexpr uint32_t kOneBits = 0x3f800000u;
+
+// diagnostic builds only (-DCT_LUT_ABLATE_LDS): every look-up reads one of two entries -> no bank conflicts, wrong
+// results; the time difference to the real build is what the conflicts cost
+#ifdef CT_LUT_ABLATE_LDS
+#define CT_LUT_OFF(off, unit) ((off) & (unit))
+#else
+#define CT_LUT_OFF(off, unit) (off)
+#endif
 
 // ---- float64-grade pieces (apply sweep) ---------------------------------------------------------------------------
 // sRGB gamma expansion of a float32 in [0,1] (c slightly outside extrapolates the end segments)
@@ -76,16 +78,17 @@ __device__ __forceinline__ double expand(const unsigned char *lds, float c) {
     const float y = fmaf(c, kAScale, kMagic);                                   // MAGIC + round(c * S)
     const uint32_t off = (__float_as_uint(y) << 4) - (kMagicBits << 4);         // 16 * index
     const float d = fmaf(y - kMagic, kANegInv, c);                              // c - index / S
-    const uint4 e = *reinterpret_cast<const uint4 *>(lds + kLdsA + off);        // one ds_read_b128: {a0 (double), a1, a2}
+    const uint4 e = *reinterpret_cast<const uint4 *>(lds + kLdsA + CT_LUT_OFF(off, 16));        // one ds_read_b128: {a0 (double), a1, a2}
     const double a0 = __hiloint2double((int)e.y, (int)e.x);
     return a0 + (double)(d * fmaf(d, __uint_as_float(e.w), __uint_as_float(e.z)));
 }
 
 // cube root of a float64 in [2^-7, 2): r = v^(-1/3) at the nearest of 256 nodes per octave, then one quadratic in v r^3
+// (one 8-byte look-up: the apply sweep is short of LDS bandwidth, not of float64 multiplies)
 __device__ __forceinline__ double cbrt_lut(const unsigned char *lds, double v) {
     const uint32_t hi = (uint32_t)__double2hiint(v);
     const uint32_t off = ((hi + (1u << (19 - kBBits))) >> (17 - kBBits)) & (((8u << kBBits) - 1u) << 3);
-    const double r = *reinterpret_cast<const double *>(lds + kLdsB + off);
+    const double r = *reinterpret_cast<const double *>(lds + kLdsB + CT_LUT_OFF(off, 8));
     const double t = v * r, b = t * r, e = b * r;
     return b * fma(fma(kBQ2, e, kBQ1), e, kBQ0);
 }
@@ -119,7 +122,7 @@ __device__ __forceinline__ float compress_clip(const unsigned char *lds, double 
     const uint32_t bits = __float_as_uint(uf) + (1u << (22 - kCBits));
     const uint32_t off = (bits >> (19 - kCBits)) & (((16u << kCBits) - 1u) << 4);
     const float d = uf - __uint_as_float(bits & ~((1u << (23 - kCBits)) - 1u));
-    const float4 e = *reinterpret_cast<const float4 *>(lds + (kLdsC - kCFirst * 16) + off);   // {a0, a1, a2, a3}
+    const float4 e = *reinterpret_cast<const float4 *>(lds + (kLdsC - kCFirst * 16) + CT_LUT_OFF(off, 16));   // {a0, a1, a2, a3}
     const float p = fmaf(d, fmaf(d, fmaf(d, e.w, e.z), e.y), e.x);
     return (uf <= 0.0031308f) ? 12.92f * uf : p;
 }
@@ -148,20 +151,18 @@ __device__ __forceinline__ void f_to_rgb_clip(const unsigned char *lds, double f
 __device__ __forceinline__ float expand32(const unsigned char *lds, float c) {
     const float y = fmaf(c, kAScale, kMagic);
     const uint32_t off = (__float_as_uint(y) << 4) - (kMagicBits << 4);
-    const float d = fmaf(y - kMagic, kANegInv, c);
-    float4 e = *reinterpret_cast<const float4 *>(lds + kLdsA + off);            // {a0, a1, a2, -}
-    asm volatile("" : "+v"(e.w));       // keeps the access one ds_read_b128 (the compiler narrows it to the slower b96)
+    const float4 e = *reinterpret_cast<const float4 *>(lds + kLdsA + CT_LUT_OFF(off, 16));      // {a0, a1, a2, node}
+    const float d = c - e.w;
     return fmaf(d, fmaf(d, e.z, e.y), e.x);
 }
 
-// cube root of a float32 in [2^-7, 2): c_i (1 + p), p = (1 + delta)^(1/3) - 1 to second order, delta = (v - v_i) / v_i <= 2^-9
+// cube root of a float32 in [2^-7, 2): quadratic around the nearest of 128 nodes per octave
 __device__ __forceinline__ float cbrt32(const unsigned char *lds, float v) {
-    const uint32_t bits = __float_as_uint(v) + (1u << (22 - kBBits));
-    const uint32_t off = (bits >> (20 - kBBits)) & (((8u << kBBits) - 1u) << 3);
-    const float d = v - __uint_as_float(bits & ~((1u << (23 - kBBits)) - 1u));  // exact
-    const float2 e = *reinterpret_cast<const float2 *>(lds + kLdsB + off);      // {c_i, 1 / v_i}
-    const float dl = d * e.y;
-    return fmaf(e.x, dl * fmaf(dl, -1.0f / 9.0f, 1.0f / 3.0f), e.x);
+    const uint32_t bits = __float_as_uint(v) + (1u << (22 - kB32Bits));
+    const uint32_t off = (bits >> (19 - kB32Bits)) & (((8u << kB32Bits) - 1u) << 4);
+    const float4 e = *reinterpret_cast<const float4 *>(lds + kLdsB + CT_LUT_OFF(off, 16));      // {c, s1, s2, node}
+    const float d = v - e.w;                                                    // exact
+    return fmaf(d, fmaf(d, e.z, e.y), e.x);
 }
 
 // matrix row in float32 with two-piece constants: a constant rounded to float32 is off by up to 3e-8 relative for EVERY
@@ -170,6 +171,10 @@ __device__ __forceinline__ float cbrt32(const unsigned char *lds, float v) {
     fmaf(lb, (float)(C), fmaf(lg, (float)(B), fmaf(lr, (float)(A),                                                                     \
          fmaf(lb, (float)((C) - (double)(float)(C)), fmaf(lg, (float)((B) - (double)(float)(B)), lr * (float)((A) - (double)(float)(A)))))))
 
+// one pixel (float32, all three in [0,1]) -> (fx, fy, fz).  The linear toe of Lab's f() is rare for most images, so it sits
+// behind one test per pixel: the selects run only when some lane of the wave needs them.  (Moving all four pixels of a
+// lane through the tables in phases -- twelve look-ups in flight -- was measured 4 % slower: more live registers, and the
+// LDS latency is already covered by the other waves.)
 __device__ __forceinline__ void rgb_to_f32(const unsigned char *lds, float r, float g, float b, float &fx, float &fy, float &fz) {
     const float lr = expand32(lds, r), lg = expand32(lds, g), lb = expand32(lds, b);
     const float x = CT_ROW32(lr, lg, lb, CT_M00, CT_M01, CT_M02);

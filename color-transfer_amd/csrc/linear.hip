@@ -135,6 +135,19 @@ __global__ __launch_bounds__(kBlock) CT_WPE void moments_kernel(const T *__restr
     }
 }
 
+// shifted sums of (fy, fx-fy, fy-fz) around pivot k over n pixels -> the Lab stats record {mean L,a,b ; std L,a,b ; n ; 0}
+__device__ __forceinline__ void lab_record(const double *s, const double *k, double n, double *o) {
+    const double m0 = s[0] / n, m1 = s[1] / n, m2 = s[2] / n;  // mean of (x - K)
+    // (fy, fx-fy, fy-fz) -> (L, a, b): scale 116/500/200, offset -16/0/0
+    o[0] = fma(116.0, k[0] + m0, -16.0); o[1] = 500.0 * (k[1] + m1); o[2] = 200.0 * (k[2] + m2);
+    // population variance (np.std, ddof 0); clamp the cancellation residue of constant images
+    const double v0 = fma(-s[0], m0, s[3]) / n, v1 = fma(-s[1], m1, s[4]) / n, v2 = fma(-s[2], m2, s[5]) / n;
+    o[3] = 116.0 * sqrt(v0 > 0.0 ? v0 : (v0 == v0 ? 0.0 : v0));
+    o[4] = 500.0 * sqrt(v1 > 0.0 ? v1 : (v1 == v1 ? 0.0 : v1));
+    o[5] = 200.0 * sqrt(v2 > 0.0 ? v2 : (v2 == v2 ? 0.0 : v2));
+    o[6] = n; o[7] = 0.0;
+}
+
 // grid = n_images, one workgroup each: adds the G partials in a fixed order and writes the record.
 template <bool LAB>
 __global__ __launch_bounds__(kBlock) void moments_finalize_kernel(const double *__restrict__ partials,
@@ -157,15 +170,7 @@ __global__ __launch_bounds__(kBlock) void moments_finalize_kernel(const double *
         const double *k = pivots + img * kPivotStride;
         const double m0 = s[0] / n, m1 = s[1] / n, m2 = s[2] / n;  // mean of (x - K)
         if (LAB) {
-            double *o = stats + (size_t)img * CT_LAB_STATS_STRIDE;
-            // (fy, fx-fy, fy-fz) -> (L, a, b): scale 116/500/200, offset -16/0/0
-            o[0] = fma(116.0, k[0] + m0, -16.0); o[1] = 500.0 * (k[1] + m1); o[2] = 200.0 * (k[2] + m2);
-            // population variance (np.std, ddof 0); clamp the cancellation residue of constant images
-            const double v0 = fma(-s[0], m0, s[3]) / n, v1 = fma(-s[1], m1, s[4]) / n, v2 = fma(-s[2], m2, s[5]) / n;
-            o[3] = 116.0 * sqrt(v0 > 0.0 ? v0 : (v0 == v0 ? 0.0 : v0));
-            o[4] = 500.0 * sqrt(v1 > 0.0 ? v1 : (v1 == v1 ? 0.0 : v1));
-            o[5] = 200.0 * sqrt(v2 > 0.0 ? v2 : (v2 == v2 ? 0.0 : v2));
-            o[6] = n; o[7] = 0.0;
+            lab_record(s, k, n, stats + (size_t)img * CT_LAB_STATS_STRIDE);
         } else {
             double *o = stats + (size_t)img * CT_RGB_STATS_STRIDE;
             o[0] = k[0] + m0; o[1] = k[1] + m1; o[2] = k[2] + m2;
@@ -346,9 +351,9 @@ __global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_STATS) void lab_moments_lut_k
                                                                                       const float *__restrict__ base1, int n_first,
                                                                                       int64_t n_pixels, double *__restrict__ partials,
                                                                                       double *__restrict__ pivots) {
-    __shared__ __attribute__((aligned(16))) unsigned char tab[lut::kLdsBytesFwd];
+    __shared__ __attribute__((aligned(16))) unsigned char tab[lut::kLdsBytesF32];
     __shared__ double red[kLutWaves * 6];
-    __shared__ double piv[3];
+    __shared__ float piv[3];
     const int img = blockIdx.y;
     const float *p = (img < n_first) ? base0 + (size_t)img * n_pixels * 3 : base1 + (size_t)(img - n_first) * n_pixels * 3;
     const int lane = threadIdx.x & (kWave - 1);
@@ -359,19 +364,30 @@ __global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_STATS) void lab_moments_lut_k
 #if CT_LUT_PREFETCH
     float nxt[12];
 #endif
-    if (t < n_full) load_tile(p + t * (kTilePixels * 3), lane, cur);          // in flight while the tables are built
+#ifdef CT_DIAG_CLOCK      // diagnostic build: shader clock held during this kernel = d(s_memtime) / d(s_memrealtime) x 100 MHz
+    const uint64_t clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (t < n_full) load_tile(p + t * (kTilePixels * 3), lane, cur);          // in flight while the tables are copied
+    float p0[3] = {0.f, 0.f, 0.f};
+    if (threadIdx.x == 0 && n_pixels > 0) { p0[0] = p[0]; p0[1] = p[1]; p0[2] = p[2]; }
     lut::load_tables_f32<kLutBlock>(tab);
-    if (threadIdx.x == 0) {                                          // pivot: pixel 0 of the image, exact arithmetic
-        double k0 = 0.0, k1 = 0.0, k2 = 0.0;
-        if (n_pixels > 0) to_space<true>((double)p[0], (double)p[1], (double)p[2], k0, k1, k2);
-        piv[0] = k0; piv[1] = k1; piv[2] = k2;
+    __syncthreads();
+    // Pivot of the shifted sums: the values of pixel 0 of the image (any point inside the data's range keeps the variance
+    // well conditioned), put on a 2^-10 grid: (a float32 difference, on a 2^-26 grid) - (a pivot with finer bits) would round
+    // the SAME way for every pixel -- a bias of half an ulp (measured: 4e-9, i.e. 2e-6 in mean a*).  Out-of-range pixel 0: 0.5.
+    if (threadIdx.x == 0) {
+        float fx = 0.5f, fy = 0.5f, fz = 0.5f;
+        if (max(max(__float_as_uint(p0[0]), __float_as_uint(p0[1])), __float_as_uint(p0[2])) <= lut::kOneBits) {
+            lut::rgb_to_f32(tab, p0[0], p0[1], p0[2], fx, fy, fz);
+        }
+        piv[0] = rintf(fy * 1024.0f) * (1.0f / 1024.0f);
+        piv[1] = rintf((fx - fy) * 1024.0f) * (1.0f / 1024.0f);
+        piv[2] = rintf((fy - fz) * 1024.0f) * (1.0f / 1024.0f);
     }
     __syncthreads();
-    const double k[3] = {uniform_f64(piv[0]), uniform_f64(piv[1]), uniform_f64(piv[2])};
-    // the pivot both accumulators share, on a 2^-10 grid: (value on the 2^-26 grid of a float32 difference) - (pivot with
-    // finer bits) would round the SAME way for every pixel -- a bias of half an ulp (measured: 4e-9, i.e. 2e-6 in mean a*)
-    const float kf[3] = {rintf((float)k[0] * 1024.0f) * (1.0f / 1024.0f), rintf((float)k[1] * 1024.0f) * (1.0f / 1024.0f),
-                         rintf((float)k[2] * 1024.0f) * (1.0f / 1024.0f)};
+    const float kf[3] = {__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(piv[0]))),
+                         __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(piv[1]))),
+                         __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(piv[2])))};
     const double kd[3] = {(double)kf[0], (double)kf[1], (double)kf[2]};
     double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     float sf[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -379,7 +395,11 @@ __global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_STATS) void lab_moments_lut_k
 #if CT_LUT_PREFETCH
         if (t + stride < n_full) load_tile(p + (t + stride) * (kTilePixels * 3), lane, nxt);
 #endif
+#ifdef CT_ABL_NOSLOW
+        if (false) {
+#else
         if (__builtin_amdgcn_ballot_w64(max_bits12(cur) > lut::kOneBits)) {
+#endif
 #pragma unroll 1
             for (int q = 0; q < 4; ++q) {
                 double x, y, z;
@@ -424,6 +444,10 @@ __global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_STATS) void lab_moments_lut_k
             pivots[img * kPivotStride + 0] = kd[0];
             pivots[img * kPivotStride + 1] = kd[1];
             pivots[img * kPivotStride + 2] = kd[2];
+#ifdef CT_DIAG_CLOCK
+            const uint64_t clk1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
+            pivots[img * kPivotStride + 3] = (double)(clk1 - clk0) / (double)(rt1 - rt0) * 0.1;     // GHz
+#endif
         }
     }
 }
@@ -433,8 +457,12 @@ template <bool OUT_LAB>
 __global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_APPLY) void reinhard_apply_lut_kernel(const float *__restrict__ target,
                                                                                          const double *__restrict__ stats_t,
                                                                                          const double *__restrict__ stats_r,
-                                                                                         float *__restrict__ out, int64_t n_pixels) {
+                                                                                         float *__restrict__ out, int64_t n_pixels,
+                                                                                         const double *__restrict__ partials,
+                                                                                         const double *__restrict__ pivots, int n_partials,
+                                                                                         int batch, double *__restrict__ stats_out) {
     __shared__ __attribute__((aligned(16))) unsigned char tab[OUT_LAB ? lut::kLdsBytesFwd : lut::kLdsBytesAll];
+    __shared__ double fin[12 * 8 + 2 * CT_LAB_STATS_STRIDE];
     const int img = blockIdx.y;
     const float *p = target + (size_t)img * n_pixels * 3;
     float *o = out + (size_t)img * n_pixels * 3;
@@ -447,8 +475,42 @@ __global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_APPLY) void reinhard_apply_lu
     float nxt[12];
 #endif
     if (t < n_full) load_tile(p + t * (kTilePixels * 3), lane, cur);
+    // Fused call (partials != NULL): the finishing step of the statistics sweep is done here, by every workgroup for its
+    // own pair -- the partial sums of the target (image img) and the reference (image batch + img) are added in a fixed
+    // order (8 interleaved chains per moment, then in chain order), identical in every workgroup -- instead of a
+    // one-workgroup-per-image kernel of its own (5.5 us + a launch boundary per call).
+    if (partials != nullptr && threadIdx.x < 96) {
+        const int g = threadIdx.x >> 3, sub = threadIdx.x & 7;          // g = which * 6 + moment
+        const int image = (g >= 6) ? batch + img : img;
+        const double *src = partials + (size_t)image * kMaxBlocksPerImage * kPartialStride + (g % 6);
+        double a = 0.0;
+        for (int b = sub; b < n_partials; b += 8) a += src[(size_t)b * kPartialStride];
+        fin[g * 8 + sub] = a;
+    }
     lut::load_tables<kLutBlock, !OUT_LAB>(tab);
-    ReinhardCoef c = reinhard_coef(stats_t + (size_t)img * CT_LAB_STATS_STRIDE, stats_r + (size_t)img * CT_LAB_STATS_STRIDE);
+    const double *rec_t = stats_t + (size_t)img * CT_LAB_STATS_STRIDE, *rec_r = stats_r + (size_t)img * CT_LAB_STATS_STRIDE;
+    if (partials != nullptr) {
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            const int image = threadIdx.x ? batch + img : img;
+            double sum[6];
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+                const double *f = fin + (threadIdx.x * 6 + m) * 8;
+                sum[m] = ((((((f[0] + f[1]) + f[2]) + f[3]) + f[4]) + f[5]) + f[6]) + f[7];
+            }
+            double *rec = fin + 96 + threadIdx.x * CT_LAB_STATS_STRIDE;
+            lab_record(sum, pivots + image * kPivotStride, (double)n_pixels, rec);
+            if (blockIdx.x == 0 && stats_out != nullptr) {
+#pragma unroll
+                for (int m = 0; m < CT_LAB_STATS_STRIDE; ++m) stats_out[(size_t)image * CT_LAB_STATS_STRIDE + m] = rec[m];
+            }
+        }
+        __syncthreads();
+        rec_t = fin + 96;
+        rec_r = fin + 96 + CT_LAB_STATS_STRIDE;
+    }
+    ReinhardCoef c = reinhard_coef(rec_t, rec_r);
     c.sL = uniform_f64(c.sL); c.sa = uniform_f64(c.sa); c.sb = uniform_f64(c.sb);
     c.cy = uniform_f64(c.cy); c.ca = uniform_f64(c.ca); c.cb = uniform_f64(c.cb);
     // the table path needs finite, moderate coefficients (then every intermediate is finite); anything else -- a
@@ -461,7 +523,11 @@ __global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_APPLY) void reinhard_apply_lu
         if (t + stride < n_full) load_tile(p + (t + stride) * (kTilePixels * 3), lane, nxt);
 #endif
         float w[12];
+#ifdef CT_ABL_NOSLOW
+        if (false) {
+#else
         if (coef_bad || __builtin_amdgcn_ballot_w64(max_bits12(cur) > lut::kOneBits)) {
+#endif
 #pragma unroll 1
             for (int q = 0; q < 4; ++q) {
                 rotate_pixels(w);                      // the result of pixel q lands in slot 3 and ends in slot q
@@ -759,7 +825,9 @@ static int lut_blocks_per_image(int resident, int64_t n_tiles, int n_images) {
 
 template <typename T, bool LAB>
 static int launch_moments(const T *base0, const T *base1, int n_first, int n_images, int64_t n_pixels,
-                          const WsLayout &l, double *stats, hipStream_t s) {
+                          const WsLayout &l, double *stats, hipStream_t s, int *deferred_partials = nullptr) {
+    // deferred_partials: the caller's next kernel finishes the statistics itself (fused table-path Reinhard); receives the
+    // number of partial sums per image, or stays 0 when this launch took a path that finishes here
     if (n_images == 0) return CT_OK;
     constexpr bool kLut = LAB && sizeof(T) == 4;
     const bool use_lut = kLut && g_lab_mode == 0;
@@ -779,6 +847,10 @@ static int launch_moments(const T *base0, const T *base1, int n_first, int n_ima
                            n_pixels, l.partials, l.pivots);
     CT_CHECK_LAUNCH();
     if (LAB && g_prof_evt[1]) (void)hipEventRecord(g_prof_evt[1], s);
+    if (use_lut && deferred_partials != nullptr && n_pixels > 0) {
+        *deferred_partials = G;
+        return CT_OK;
+    }
     hipLaunchKernelGGL((moments_finalize_kernel<LAB>), dim3(n_images), dim3(kBlock), 0, s, l.partials, l.pivots, G,
                        n_pixels, stats);
     CT_CHECK_LAUNCH();
@@ -787,7 +859,8 @@ static int launch_moments(const T *base0, const T *base1, int n_first, int n_ima
 
 template <typename T, bool OUT_LAB>
 static int launch_reinhard_apply(const T *target, const double *st, const double *sr, T *out, int64_t n_pixels,
-                                 int batch, hipStream_t s) {
+                                 int batch, hipStream_t s, const WsLayout *deferred = nullptr, int n_partials = 0,
+                                 double *stats_out = nullptr) {
     if (batch == 0 || n_pixels == 0) return CT_OK;
     constexpr bool kLut = sizeof(T) == 4;
     const bool use_lut = kLut && g_lab_mode == 0;
@@ -800,7 +873,8 @@ static int launch_reinhard_apply(const T *target, const double *st, const double
     if constexpr (kLut) {
         if (use_lut)
             hipLaunchKernelGGL((reinhard_apply_lut_kernel<OUT_LAB>), dim3(G, batch), dim3(kLutBlock), 0, s, target, st, sr, out,
-                               n_pixels);
+                               n_pixels, (const double *)(deferred ? deferred->partials : nullptr),
+                               (const double *)(deferred ? deferred->pivots : nullptr), n_partials, batch, stats_out);
     }
     if (!use_lut)
         hipLaunchKernelGGL((reinhard_apply_kernel<T, OUT_LAB>), dim3(G, batch), dim3(kBlock), 0, s, target, st, sr, out,
@@ -844,10 +918,11 @@ static int reinhard_impl(const T *target, const T *reference, T *out, int64_t n_
     const WsLayout l = ws_carve(ws, 2 * batch);
     // one sweep over all 2*batch images; stats records [0,batch) = targets, [batch,2batch) = references
     double *stats = stats_out ? stats_out : l.stats;
-    rc = launch_moments<T, true>(target, reference, batch, 2 * batch, n_pixels, l, stats, (hipStream_t)stream);
+    int deferred = 0;      // > 0: table path, the apply kernel finishes the statistics in its prologue (and writes stats_out)
+    rc = launch_moments<T, true>(target, reference, batch, 2 * batch, n_pixels, l, stats, (hipStream_t)stream, &deferred);
     if (rc) return rc;
     return launch_reinhard_apply<T, false>(target, stats, stats + (size_t)batch * CT_LAB_STATS_STRIDE, out, n_pixels,
-                                           batch, (hipStream_t)stream);
+                                           batch, (hipStream_t)stream, deferred > 0 ? &l : nullptr, deferred, stats);
 }
 
 template <typename TI, typename TO>

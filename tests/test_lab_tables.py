@@ -29,7 +29,7 @@ def test_header_is_generated(gen, tables):
 
 
 def test_table_accuracy_bounds(gen, tables):
-    err_a, rel_b, err_c = gen.verify(*tables, verbose=False)
+    err_a, rel_b, err_c = gen.verify(*tables, verbose=False)    # also asserts the float32 tables A32 / B32 (<= 2 ulp)
     assert err_a < 3e-10        # linear values, absolute
     assert rel_b < 2e-9         # cube roots, relative
     assert err_c < 1.3e-7       # gamma compression, absolute (float32 result)
@@ -47,7 +47,7 @@ def test_kink_sits_on_a_grid_boundary(gen, tables):
 def test_lab_from_tables_vs_oracle(gen, tables):
     """rgb -> Lab through the emulated tables against the float64 oracle on random, 8-bit and dark pixels"""
     from oracle import lab as olab
-    ta, tb, _ = tables
+    ta, tb = tables[0], tables[1]
     rng = np.random.default_rng(3)
     rgb = np.concatenate([rng.random((20000, 3), dtype=np.float32), rng.integers(0, 256, (5000, 3)).astype(np.float32) / 255,
                           rng.random((5000, 3), dtype=np.float32) * np.float32(0.1)])

@@ -11,6 +11,8 @@ reference calls them (methods/linear.py:25,26,40):
      value = a0 + d*(a1 + d*a2), d = c - idx/S.
   B  r = v**(-1/3) at the nodes of a log grid (256 nodes per octave, v in [2^-7, 2)), doubles.
      cbrt(v) = b*g(e) with b = v r^2, e = b r = v r^3 in 1 +- 2^-9 and g(e) = e**(-2/3) as ONE quadratic.
+  A32, B32  float32 images of A and of the cube root for the statistics sweep (which only needs unbiased per-pixel values):
+     {a0, a1, a2, node} and {c, s1, s2, node}: value = c + d*(s1 + d*s2), d = x - node; B32 has 128 nodes per octave.
   C  sRGB gamma compression u -> 1.055*u**(1/2.4) - 0.055 on a log grid (32 nodes per octave, u in [2^-9, 1]),
      float32 cubics {a0,a1,a2,a3} in d = u - node (the result is rounded to float32 anyway).
 
@@ -36,6 +38,7 @@ MAGIC = np.float32(12582912.0)   # 1.5 * 2^23: float32 ulp there is 1.0
 
 B_BITS = 8                # table B: mantissa bits per octave (256 nodes)
 B_EXP0 = 1016             # biased double exponent of 2^-7; 8 octaves -> v in [2^-7, 2)
+B32_BITS = 7              # table B32: 128 nodes per octave (float32 statistics sweep)
 C_BITS = 5                # table C: 32 nodes per octave
 C_EXP0 = 112              # table C is addressed with (exp & 15): 16 octaves from biased float exponent 112 (2^-15)
 C_EXP_FIRST = 118         # first octave that is actually filled: 2^-9 <= 0.0031308
@@ -156,6 +159,56 @@ def emulate_b(tab, v):
     return b * g
 
 
+def build_table_a32(ta):
+    """float32 image of table A: the node index / S is rounded to float32 and a0 moves with it (a0 + a1 * shift)"""
+    n = ta["n"]
+    out = np.zeros((n, 4), np.float32)
+    for i in range(n):
+        node = mp.mpf(i) * mp.mpf(ta["inv"])
+        nodef = np.float32(float(node))
+        shift = mp.mpf(float(nodef)) - node
+        a0 = mp.mpf(float(ta["a0"][i])) + mp.mpf(float(ta["a1"][i])) * shift + mp.mpf(float(ta["a2"][i])) * shift * shift
+        a1 = mp.mpf(float(ta["a1"][i])) + 2 * mp.mpf(float(ta["a2"][i])) * shift
+        out[i] = [np.float32(float(a0)), np.float32(float(a1)), ta["a2"][i], nodef]
+    return out
+
+
+def build_table_b32():
+    n = 8 << B32_BITS
+    out = np.zeros((n, 4), np.float32)
+    for i in range(n):
+        e = 120 + (i >> B32_BITS) - 127
+        m = i & ((1 << B32_BITS) - 1)
+        v = mp.mpf(2) ** e * (1 + mp.mpf(m) / (1 << B32_BITS))
+        step = mp.mpf(2) ** e / (1 << B32_BITS)
+        lo = -step / 2 if m else -step / 4
+        q = interp_poly(lambda d: mp.cbrt(v + d), lo * mp.mpf("1.01"), step / 2 * mp.mpf("1.01"), 2)
+        out[i] = [np.float32(float(q[0])), np.float32(float(q[1])), np.float32(float(q[2])), np.float32(float(v))]
+    return out
+
+
+def fma32(a, b, c):
+    return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(np.float32)
+
+
+def emulate_a32(ta, a32, c32):
+    c32 = np.asarray(c32, np.float32)
+    y = fma32(c32, np.float32(ta["S"]), MAGIC)
+    idx = y.view(np.uint32).astype(np.int64) - f32_bits(MAGIC)
+    e = a32[idx]
+    d = (c32 - e[:, 3]).astype(np.float32)
+    return fma32(d, fma32(d, e[:, 2], e[:, 1]), e[:, 0])
+
+
+def emulate_b32(b32, v32):
+    v32 = np.asarray(v32, np.float32)
+    bits = v32.view(np.uint32).astype(np.int64) + (1 << (22 - B32_BITS))
+    idx = (bits >> (23 - B32_BITS)) & ((8 << B32_BITS) - 1)
+    e = b32[idx]
+    d = (v32 - e[:, 3]).astype(np.float32)
+    return fma32(d, fma32(d, e[:, 2], e[:, 1]), e[:, 0])
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # table C
 # ---------------------------------------------------------------------------------------------------------------------
@@ -199,7 +252,7 @@ def emulate_c(tab, u32):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def verify(ta, tb, tc, verbose=True):
+def verify(ta, tb, tc, a32=None, b32=None, verbose=True):
     rng = np.random.default_rng(7)
     # A: all float32 values around the kink must land on the right side; dense accuracy check
     c_lo = np.float32(KINK_A)
@@ -225,6 +278,18 @@ def verify(ta, tb, tc, verbose=True):
     want = np.array([float(mp.mpf("12.92") * mp.mpf(float(u)) if float(u) <= KINK_C else srgb_compress_pow(float(u))) for u in us])
     err_c = np.abs(got.astype(np.float64) - want).max()
     assert emulate_c(tc, np.float32([1.0, 2.0]))[0] == 1.0
+    if a32 is not None:
+        c = np.concatenate([rng.random(40000, dtype=np.float32), (np.arange(256) / 255.0).astype(np.float32)])
+        want = np.array([float(srgb_expand(float(x))) for x in c])
+        rel_a32 = np.abs(emulate_a32(ta, a32, c).astype(np.float64) - want) / np.maximum(want, 1e-30)
+        vv = np.exp(rng.uniform(np.log(0.008856), 0.0, 40000)).astype(np.float32)
+        want = np.array([float(mp.cbrt(mp.mpf(float(x)))) for x in vv])
+        rel_b32 = np.abs(emulate_b32(b32, vv).astype(np.float64) / want - 1)
+        if verbose:
+            print("tables A32 / B32: max rel err %.3g / %.3g, mean signed rel err %.2g / %.2g (float32 ulp 6e-8 .. 1.2e-7)" % (
+                rel_a32.max(), rel_b32.max(), ((emulate_a32(ta, a32, c).astype(np.float64) - np.array([float(srgb_expand(float(x))) for x in c])) / np.maximum(np.array([float(srgb_expand(float(x))) for x in c]), 1e-30)).mean(),
+                (emulate_b32(b32, vv).astype(np.float64) / want - 1).mean()))
+        assert rel_a32[c > 1e-3].max() < 2.5e-7 and rel_b32.max() < 1.5e-7
     if verbose:
         print("table A: S=%.9g k=%d n=%d   max abs err %.3g, max rel err (c>0.05) %.3g" % (ta["S"], ta["k"], ta["n"], err_a.max(), rel_a))
         print("table B: n=%d  cbrt max rel err %.3g   q=%s" % (tb["n"], rel_b, tb["q"]))
@@ -239,7 +304,7 @@ def hexd(x):
     return float(x).hex()
 
 
-def render(ta, tb, tc):
+def render(ta, tb, tc, a32, b32):
     L = []
     w = L.append
     w("// ct_lab_tables.h -- GENERATED by tools/gen_lab_tables.py (do not edit; `python tools/gen_lab_tables.py` rewrites it).")
@@ -259,6 +324,9 @@ def render(ta, tb, tc):
     w("constexpr int kCEntries = %d;          // addressed with (exponent & 15): entries below %d are never read" % (tc["last"] + 1, tc["first"]))
     w("struct alignas(16) EntryA { double a0; float a1, a2; };")
     w("struct alignas(16) EntryC { float a0, a1, a2, a3; };")
+    w("struct alignas(16) Entry32 { float c, s1, s2, node; };   // value = c + d * (s1 + d * s2), d = x - node")
+    w("constexpr int kB32Bits = %d;" % B32_BITS)
+    w("constexpr int kB32Entries = %d;" % len(b32))
     w("")
     w("__device__ const EntryA kTableA[kAEntries] = {")
     for i in range(ta["n"]):
@@ -272,18 +340,27 @@ def render(ta, tb, tc):
     for i in range(tc["last"] + 1):
         w("  {%sf, %sf, %sf, %sf}," % tuple(hexd(x) for x in tc["a"][i]))
     w("};")
+    w("__device__ const Entry32 kTableA32[kAEntries] = {")
+    for i in range(len(a32)):
+        w("  {%sf, %sf, %sf, %sf}," % tuple(hexd(x) for x in a32[i]))
+    w("};")
+    w("__device__ const Entry32 kTableB32[kB32Entries] = {")
+    for i in range(len(b32)):
+        w("  {%sf, %sf, %sf, %sf}," % tuple(hexd(x) for x in b32[i]))
+    w("};")
     w("}}  // namespace ct::lut")
     return "\n".join(L) + "\n"
 
 
 def build_all():
-    return build_table_a(), build_table_b(), build_table_c()
+    ta = build_table_a()
+    return ta, build_table_b(), build_table_c(), build_table_a32(ta), build_table_b32()
 
 
 def main():
-    ta, tb, tc = build_all()
-    verify(ta, tb, tc)
-    text = render(ta, tb, tc)
+    tabs = build_all()
+    verify(*tabs)
+    text = render(*tabs)
     if "--check" in sys.argv:
         same = os.path.exists(HEADER) and open(HEADER).read() == text
         print("header up to date" if same else "HEADER DIFFERS from the generator output")
