@@ -15,8 +15,10 @@ def _resb(sd, name, x):
     return x + _conv(sd, name + ".body.2", t, 1)
 
 
-def forward(sd, left, right, extraction_layers=18, transfer_layers=6):
-    """Returns a dict with the same intermediates the goldens hold. sd: name -> tensor."""
+def forward(sd, left, right, extraction_layers=18, transfer_layers=6, valid_override=None):
+    """Returns a dict with the same intermediates the goldens hold. sd: name -> tensor.
+    valid_override: a boolean [B,1,H,W] mask used in place of `colsum > 0.1` (the threshold is discontinuous: a test that
+    wants to compare the arithmetic behind it feeds both sides the same mask); adds `pre_clamp_override` to the result."""
     left, right = left.double(), right.double()
 
     def extraction(x):
@@ -44,12 +46,17 @@ def forward(sd, left, right, extraction_layers=18, transfer_layers=6):
         return torch.matmul(att, img.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
 
     fea_warped = warp(_conv(sd, "matcher.value", fea_right, 0), att_r2l)
-    x = torch.cat([fea_left, fea_warped, valid_left.double()], dim=1)
-    x = _conv(sd, "transfer.0", x, 0)
-    for i in range(1, transfer_layers + 1):
-        x = _resb(sd, "transfer.%d" % i, x)
-    x = _conv(sd, "transfer.%d" % (transfer_layers + 1), x, 1)
-    pre = _conv(sd, "transfer.%d" % (transfer_layers + 2), x, 1)
-    return dict(fea_left=fea_left, fea_right=fea_right, cost_r2l=cost_r2l, cost_l2r=cost_l2r, att_r2l=att_r2l,
+
+    def transfer(valid):
+        x = torch.cat([fea_left, fea_warped, valid.double()], dim=1)
+        x = _conv(sd, "transfer.0", x, 0)
+        for i in range(1, transfer_layers + 1):
+            x = _resb(sd, "transfer.%d" % i, x)
+        x = _conv(sd, "transfer.%d" % (transfer_layers + 1), x, 1)
+        return _conv(sd, "transfer.%d" % (transfer_layers + 2), x, 1)
+
+    pre = transfer(valid_left)
+    extra = {} if valid_override is None else {"pre_clamp_override": transfer(valid_override)}
+    return dict(extra, fea_left=fea_left, fea_right=fea_right, cost_r2l=cost_r2l, cost_l2r=cost_l2r, att_r2l=att_r2l,
                 att_l2r=att_l2r, colsum=colsum, valid_left=valid_left, fea_warped=fea_warped, pre_clamp=pre,
                 corrected=pre.clamp(0, 1), warped_rgb=warp(right, att_r2l))

@@ -11,6 +11,19 @@ torch = pytest.importorskip("torch")
 from tests.gmflow_common import procedural_state, test_pair as make_pair   # noqa: E402
 
 
+# asserted per-stage bounds (pixels for the flow stages), per convolution mode; see test_gmflow_vs_reference
+STAGE_BOUNDS = {   # measured round 2 (worst of the two goldens): see the comment row under each bound
+    "split": {"backbone 1/8": 7e-5, "backbone 1/4": 7e-5, "transformer s0": 1.1e-4, "global match": 3.2e-3, "propagation s0": 1.6e-4,
+              # measured      3.2e-5               3.1e-5                  5.2e-5                 1.55e-3                  7.6e-5
+              "transformer s1": 3.5e-4, "local match": 1.5e-2, "propagation s1": 6.5e-3, "refine": 7e-3, "flow": 5e-2, "flow_bwd": 2.5e-2},
+    #          measured 1.6e-4              7.1e-3                  3.1e-3                   3.3e-3        2.3e-2        1.2e-2
+    "exact": {"backbone 1/8": 7e-5, "backbone 1/4": 7e-5, "transformer s0": 1.1e-4, "global match": 2.4e-3, "propagation s0": 1.6e-4,
+              # measured      3.0e-5               3.1e-5                  4.2e-5                 1.2e-3                   6.2e-5
+              "transformer s1": 4.1e-4, "local match": 8e-3, "propagation s1": 7e-3, "refine": 7.1e-3, "flow": 5e-2, "flow_bwd": 2.2e-2},
+    #          measured 2.0e-4              3.8e-3                3.4e-3                  3.5e-3          2.3e-2        1.1e-2
+}
+
+
 def _g(golden_dir):
     return np.load(os.path.join(golden_dir, "gmflow_small.npz"), allow_pickle=False)
 
@@ -35,22 +48,27 @@ def test_gmflow_vs_reference(golden_dir, tag, hw, seed, conv_mode):
     dbg = {}
     res = m(img0.cuda(), img1.cuda(), inference_size=size, pred_bidir_flow=True, fwd_bwd_consistency_check=True, dbg=dbg)
 
-    def chk(a, b, msg, rtol, atol):
-        np.testing.assert_allclose(a.cpu().numpy(), b, rtol=rtol, atol=atol, err_msg=msg)
-    # tolerances = a few times the float32-vs-float64 spread of this graph (tests/gmflow_common.py), i.e. rounding level
-    chk(dbg["feat_s0"][:, ::16], g[tag + "/feat_s0_c16"], "backbone 1/8", 2e-4, 2e-4)
-    chk(dbg["feat_s1"][:, ::16], g[tag + "/feat_s1_c16"], "backbone 1/4", 2e-4, 2e-4)
-    chk(dbg["tf0_s0"][:, ::16], g[tag + "/tf0_s0_c16"], "transformer s0", 1e-3, 1e-3)
-    chk(dbg["flow_match_s0"], g[tag + "/flow_match_s0"], "global match", 1e-3, 1e-2)
-    chk(dbg["flow_prop_s0"], g[tag + "/flow_prop_s0"], "propagation s0", 1e-3, 1e-2)
-    chk(dbg["tf0_s1"][:, ::16], g[tag + "/tf0_s1_c16"], "transformer s1", 2e-3, 5e-3)
-    chk(dbg["flow_match_s1"], g[tag + "/flow_match_s1"], "local match", 1e-3, 1e-1)
-    chk(dbg["flow_prop_s1"], g[tag + "/flow_prop_s1"], "propagation s1", 1e-3, 1e-1)
-    for i in range(6):
-        chk(dbg["flow_refine_%d" % i], g[tag + "/flow_refine_%d" % i], "refine %d" % i, 2e-3, 1e-1)
-    chk(res["flow"], g[tag + "/flow"], "flow", 2e-3, 3e-1)
-    chk(res["flow_bwd"], g[tag + "/flow_bwd"], "flow_bwd", 2e-3, 3e-1)
+    # Achieved max-abs error per stage against the reference run (float32 CPU), and the bound asserted for it: at most
+    # ~2x what was measured on MI355X in round 2 (printed below on every run; a regression of that size fails).  The
+    # bounds grow along the graph because this ~150-layer RANDOM-weight network amplifies float32 rounding: the reference
+    # itself moves by 1.4e-4 / 2e-3 px / 5e-2 px (transformer / global match / final flow) between float32 and float64
+    # (tests/gmflow_common.py), which is the floor any float32 implementation sits on.
+    stages = [("backbone 1/8", dbg["feat_s0"][:, ::16], "feat_s0_c16"), ("backbone 1/4", dbg["feat_s1"][:, ::16], "feat_s1_c16"),
+              ("transformer s0", dbg["tf0_s0"][:, ::16], "tf0_s0_c16"), ("global match", dbg["flow_match_s0"], "flow_match_s0"),
+              ("propagation s0", dbg["flow_prop_s0"], "flow_prop_s0"), ("transformer s1", dbg["tf0_s1"][:, ::16], "tf0_s1_c16"),
+              ("local match", dbg["flow_match_s1"], "flow_match_s1"), ("propagation s1", dbg["flow_prop_s1"], "flow_prop_s1")]
+    stages += [("refine %d" % i, dbg["flow_refine_%d" % i], "flow_refine_%d" % i) for i in range(6)]
+    stages += [("flow", res["flow"], "flow"), ("flow_bwd", res["flow_bwd"], "flow_bwd")]
+    achieved = {name: float(np.abs(a.cpu().numpy().astype(np.float64) - g[tag + "/" + key]).max()) for name, a, key in stages}
+    bound = STAGE_BOUNDS[conv_mode]
+    print("\n[gmflow %s, %s convs] max-abs error per stage (bound):" % (tag, conv_mode))
+    for name, _, _ in stages:
+        print("   %-15s %.2e  (%.0e)" % (name, achieved[name], bound[name.split(" ")[0] if name.startswith("refine") else name]))
+    for name, _, _ in stages:
+        assert achieved[name] <= bound[name.split(" ")[0] if name.startswith("refine") else name], (name, achieved[name])
     assert res["fwd_occ"].shape == (1, 1) + hw
+    # with random weights every pixel fails the consistency check (the golden generator prints occ frac 1.000): this only
+    # checks the plumbing; the mask ARITHMETIC is pinned by tests/test_gmflow_ops_golden.py on mixed masks
     assert (res["fwd_occ"].cpu().numpy() == g[tag + "/fwd_occ"]).mean() > 0.99
 
 
