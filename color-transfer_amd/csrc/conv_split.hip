@@ -72,7 +72,11 @@ __device__ __forceinline__ void split3x2(float x0, float x1, unsigned int &hw, u
 // (it cannot tell which ones alias), i.e. the streaming wave would wait out the full L2 latency of the loads it has
 // just issued; here the landing is awaited explicitly, with a counted vmcnt, right before the publishing barrier.
 __device__ __forceinline__ void glds16(const void *gsrc, unsigned int lds_addr) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_addr) : "memory");   // m0 is not used by anything else in this kernel (checked in the ISA)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_addr) : "memory");
+    // m0 is written above.  It cannot be declared: hipcc rejects "m0" in a clobber list ("reserved register", ignored
+    // with a warning) -- the compiler never allocates m0 and only sets it itself right in front of the few instructions
+    // that read it (LDS-DMA builtins, s_movrel, s_sendmsg), none of which this kernel uses (checked in the ISA:
+    // `make asm`, then `grep -n m0 build/conv_split*.s` shows only this s_mov_b32).
 }
 
 // wp : bf16 bit patterns [group][chunk16][tap][piece][m][lane = 32*khalf + cout%32][8 channels]   (host: pack_conv_weight_split)

@@ -447,6 +447,8 @@ def _nchw_bstride(t):
 
 def conv2d(x, wp, bias, cout, ksize, act=0, residual=None, clamp=False, out=None):
     """Conv2d(ksize, padding=ksize//2) + bias [+ LeakyReLU(0.01)] [+ residual] [clamp 0..1], float32 NCHW."""
+    if x.is_cuda:
+        _check_device(x)
     if not x.is_cuda or x.dtype != torch.float32:
         raise CtHipError("conv2d needs float32 CUDA tensors (no CPU path)")
     n, cin, h, w = x.shape
@@ -465,6 +467,8 @@ def conv2d(x, wp, bias, cout, ksize, act=0, residual=None, clamp=False, out=None
 def pam_attend(q, k, v, rgb, want_att=False):
     """softmax(q.k/c) @ [v | rgb] per image row (pasmnet/attention.py:39-41, utils.py:30,123-125)."""
     for t in (q, k, v, rgb):
+        if t.is_cuda:
+            _check_device(t)
         if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
             raise CtHipError("pam_attend needs contiguous float32 CUDA tensors")
     n, c, h, w = q.shape
@@ -480,6 +484,8 @@ def pam_attend(q, k, v, rgb, want_att=False):
 def pam_valid(q, k, want_att=False):
     """valid mask (as 0/1 float [n,1,h,w]) + pre-threshold column sums of softmax(q.k/c) (utils.py:31,34-35)."""
     for t in (q, k):
+        if t.is_cuda:
+            _check_device(t)
         if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
             raise CtHipError("pam_valid needs contiguous float32 CUDA tensors")
     n, c, h, w = q.shape
@@ -527,6 +533,8 @@ def _f32c(*ts):
     for t in ts:
         if t is None:
             continue
+        if t.is_cuda:
+            _check_device(t)
         if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
             raise CtHipError("needs contiguous float32 CUDA tensors (no CPU path)")
 

@@ -18,7 +18,7 @@ import scipy.stats
 import torch
 
 import ct_hip
-from methods.linear import _as_float, _device
+from methods.linear import _as_raw_float, _device
 
 __all__ = ["iterative_distribution_transfer", "draw_rotations"]
 
@@ -37,13 +37,19 @@ def iterative_distribution_transfer_cuda(target, reference, bins=255, n_iter=4, 
     """Device-resident IDT: CUDA tensors [H,W,3] / [B,H,W,3] in, float64 tensor out (asynchronous)."""
     if rotations is None:
         rotations = draw_rotations(n_iter)
+    if tuple(rotations.shape)[-3] == 0:             # n_iter = 0: the reference's loop body never runs
+        res = target.double()
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
     return ct_hip.idt(target, reference, rotations, bins=bins, out=out)
 
 
 def iterative_distribution_transfer(target, reference, bins=255, n_iter=4, rotations=None):
     """Iterative Distribution Transfer (Pitie et al. 2007) -- reference methods/iterative.py:8-59."""
-    target = _as_float(target)
-    reference = _as_float(reference)
+    target = _as_raw_float(target)                  # no rescaling: integer frames keep their scale (iterative.py:31-55)
+    reference = _as_raw_float(reference)
     shape = target.shape
     if shape[-1] != 3:
         raise ValueError("only 3-channel images are supported (n_dims = 3)")

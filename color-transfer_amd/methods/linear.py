@@ -39,6 +39,16 @@ def _as_float(arr):
     return arr.astype(np.float64)
 
 
+def _as_raw_float(arr):
+    """What Xiao / MK / IDT see in the reference (methods/linear.py:45-124, iterative.py:8-59): NO img_as_float -- only
+    Reinhard goes through skimage's rgb2lab -- so integer frames keep their 0..255 (0..65535) scale; np.cov / the
+    rotations upcast to float64."""
+    arr = np.asanyarray(arr)
+    if arr.shape[-1] != 3:
+        raise ValueError("Input array must have a shape == (..., 3)), got %s" % (arr.shape,))
+    return arr if arr.dtype in (np.float32, np.float64) else arr.astype(np.float64)
+
+
 def _device():
     if not torch.cuda.is_available():
         raise ct_hip.CtHipError("methods.linear needs an MI355X (no CPU fallback); torch.cuda.is_available() is False")
@@ -68,19 +78,20 @@ def color_transfer_between_images_cuda(target, reference, out=None):
 def color_transfer_between_images(target, reference):
     """Color Transfer between Images (Reinhard et al. 2001) -- reference methods/linear.py:8-42.
 
-    Output has the float dtype of the target (skimage keeps float32) and is clipped to [0,1]
-    (skimage xyz2rgb).  Arithmetic is float64 on the device whatever the I/O dtype.
+    Output dtype = np.result_type(target, reference) after img_as_float (skimage keeps float32; the reference's
+    `(t - mean_t) * std_r / std_t + mean_r` promotes to float64 as soon as one side is float64) and is clipped to [0,1]
+    (skimage xyz2rgb).
     """
     target = _as_float(target)
     reference = _as_float(reference)
     shape = target.shape
-    if target.size == 0:
-        return np.empty(shape, dtype=target.dtype)
     dt = np.result_type(target.dtype, reference.dtype)
+    if target.size == 0:
+        return np.empty(shape, dtype=dt)
     t = _to_device(target, dt)
     r = _to_device(reference, dt)
     out = color_transfer_between_images_cuda(t, r)
-    return out.cpu().numpy().reshape(shape).astype(target.dtype, copy=False)
+    return out.cpu().numpy().reshape(shape)             # numpy promotion like the reference: float32 only if BOTH are float32
 
 
 # ------------------------------------------------------------------------------------------------
@@ -157,8 +168,8 @@ def monge_kantorovitch_color_transfer_cuda(target, reference, decomposition="MK"
 def color_transfer_in_correlated_color_space(target, reference):
     """Color Transfer in Correlated Color Space (Xiao & Ma 2006) -- reference methods/linear.py:45-82.
     Returns float64, unclipped (np.cov upcasts; the caller clamps, methods/__init__.py:30)."""
-    target = _as_float(target)
-    reference = _as_float(reference)
+    target = _as_raw_float(target)
+    reference = _as_raw_float(reference)
     shape = target.shape
     out = color_transfer_in_correlated_color_space_cuda(_to_device(target), _to_device(reference))
     return out.cpu().numpy().reshape(shape)
@@ -169,8 +180,8 @@ def monge_kantorovitch_color_transfer(target, reference, decomposition="MK"):
     methods/linear.py:85-124.  Returns float64, unclipped."""
     if decomposition not in ("cholesky", "sqrt", "MK"):
         raise ValueError("Unknown decomposition, use either 'cholesky', 'sqrt', or 'MK'")
-    target = _as_float(target)
-    reference = _as_float(reference)
+    target = _as_raw_float(target)
+    reference = _as_raw_float(reference)
     shape = target.shape
     # the numpy drop-in keeps the reference's own LAPACK/scipy calls for the 3x3 algebra
     out = monge_kantorovitch_color_transfer_cuda(_to_device(target), _to_device(reference), decomposition, host_algebra=True)

@@ -15,12 +15,16 @@ import yaml
 
 
 def _set(cfg, dotted, value):
+    """`--model.func_spec X`, `--model.init_args.func_spec X` (LightningCLI's canonical form) and `--model.class_path X`"""
     keys = dotted.split(".")
-    node = cfg
+    node, in_init = cfg, False
     for k in keys[:-1]:
+        if in_init and k == "init_args":
+            continue                                  # already inside init_args: the explicit component is redundant
         node = node.setdefault(k, {})
-        if k in ("model", "data") and "init_args" in node and keys[-1] not in ("class_path",):
-            node = node["init_args"]
+        if k in ("model", "data") and keys[-1] != "class_path":
+            node = node.setdefault("init_args", {})
+            in_init = True
     node[keys[-1]] = yaml.safe_load(value)
 
 
@@ -34,6 +38,8 @@ def main(argv=None):
     if not argv or argv[0] != "test":
         raise SystemExit("only the `test` sub-command exists here (fit/validate/predict are Lightning training paths)")
     cfg, ckpt, i = {}, None, 1
+    if (len(argv) - 1) % 2:
+        raise SystemExit("arguments come in `--key value` pairs; got a dangling %r" % argv[-1])
     while i < len(argv):
         key, val = argv[i], argv[i + 1]
         if key == "--config":
@@ -54,7 +60,13 @@ def main(argv=None):
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     model = _instantiate(cfg["model"]).to(device).eval()
     if ckpt:
-        model.load_state_dict(torch.load(ckpt, map_location=device)["state_dict"], strict=True)
+        # Lightning checkpoints carry hyper-parameters / optimizer state next to "state_dict": not loadable with
+        # weights_only=True in general; a checkpoint path given on the command line is a trusted local file
+        try:
+            state = torch.load(ckpt, map_location=device, weights_only=True)
+        except Exception:
+            state = torch.load(ckpt, map_location=device, weights_only=False)
+        model.load_state_dict(state["state_dict"] if "state_dict" in state else state, strict=True)
     data_cfg = dict(cfg.get("data", {}))
     data_cfg["class_path"] = "utils.data.DataModule"
     frames = _instantiate(data_cfg).test_frames()

@@ -13,6 +13,8 @@ Only inputs/outputs (data) are written; no reference source is copied.
 Outputs: tests/golden/linear_small.npz   full arrays at 48x64 (float inputs)
          tests/golden/linear_u8_256.npz  full arrays at 256x256 (k/255 inputs, stored as uint8)
          tests/golden/linear_1080p.npz   stats + strided samples at 1080x1920 (inputs re-derived from the seed)
+         tests/golden/linear_dtypes.npz  raw uint8 frames through Xiao / MK (no img_as_float there: 0..255 scale) and
+                                         Reinhard with mixed float32 / float64 arguments (numpy promotion of the result)
 """
 import hashlib
 import importlib.util
@@ -132,6 +134,22 @@ def main():
     for k in ("reinhard", "reinhard_lab", "xiao", "mk_MK", "reinhard_f32in"):
         keep[k + "_samples"] = res[k].reshape(-1, 3)[idx]
     np.savez_compressed(os.path.join(OUT, "linear_1080p.npz"), meta=str(META), **keep)
+
+    # ---- dtype rules: raw uint8 through Xiao / MK, mixed float dtypes through Reinhard -----------------------------------
+    rng = np.random.default_rng(77)
+    t8 = rng.integers(0, 256, (24, 40, 3), dtype=np.uint8)
+    r8 = np.clip(rng.integers(0, 256, (24, 40, 3)) * 0.6 + 60, 0, 255).astype(np.uint8)
+    keep = {"t8": t8, "r8": r8}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        keep["xiao_u8"] = lin.color_transfer_in_correlated_color_space(t8, r8)
+        keep["mk_u8"] = lin.monge_kantorovitch_color_transfer(t8, r8)
+        keep["reinhard_u8"] = lin.color_transfer_between_images(t8, r8)
+        t32, r64 = (t8 / 255).astype(np.float32), (r8 / 255).astype(np.float64)
+        keep["reinhard_f32_f64"] = lin.color_transfer_between_images(t32, r64)
+        keep["reinhard_f64_f32"] = lin.color_transfer_between_images(t32.astype(np.float64), r64.astype(np.float32))
+    print("dtype rules:", {k: str(v.dtype) for k, v in keep.items()}, "xiao_u8 range %.1f..%.1f" % (keep["xiao_u8"].min(), keep["xiao_u8"].max()))
+    np.savez_compressed(os.path.join(OUT, "linear_dtypes.npz"), meta=str(META), **keep)
     print("wrote goldens with", META)
 
 

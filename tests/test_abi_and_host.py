@@ -95,6 +95,38 @@ def test_host_rules_linear():
     assert out.shape == (0, 5, 3)
 
 
+def test_dtype_rules_follow_the_reference():
+    """only Reinhard goes through img_as_float (skimage rgb2lab); Xiao / MK / IDT see integer frames on their own scale"""
+    import methods.linear as lin
+    u8 = np.arange(24, dtype=np.uint8).reshape(2, 4, 3)
+    assert lin._as_float(u8).max() == 23 / 255.0 and lin._as_raw_float(u8).max() == 23.0
+    assert lin._as_raw_float(u8).dtype == np.float64 and lin._as_raw_float(u8.astype(np.float32)).dtype == np.float32
+    with pytest.raises(ValueError):
+        lin._as_raw_float(np.zeros((2, 2, 4)))
+    out = lin.color_transfer_between_images(np.zeros((0, 5, 3), np.float32), np.zeros((2, 2, 3), np.float64))
+    assert out.dtype == np.float64                    # numpy promotion of the reference's Lab arithmetic
+
+
+def test_cli_override_syntax():
+    from utils import cli
+    cfg = {"model": {"class_path": "methods.Runner", "init_args": {"func_spec": "a.b"}}, "data": {"init_args": {"num_workers": 0}}}
+    cli._set(cfg, "model.func_spec", "x.y")
+    assert cfg["model"]["init_args"]["func_spec"] == "x.y"
+    cli._set(cfg, "model.init_args.func_spec", "p.q")                # LightningCLI's canonical spelling
+    assert cfg["model"]["init_args"] == {"func_spec": "p.q"}
+    cli._set(cfg, "data.init_args.n_frames", "5")
+    cli._set(cfg, "data.height", "64")
+    assert cfg["data"]["init_args"] == {"num_workers": 0, "n_frames": 5, "height": 64}
+    cli._set(cfg, "model.class_path", "methods.dcmcs3di.DCMCS3DI")
+    assert cfg["model"]["class_path"] == "methods.dcmcs3di.DCMCS3DI" and "class_path" not in cfg["model"]["init_args"]
+    cli._set(cfg, "trainer.logger", "false")
+    assert cfg["trainer"] == {"logger": False}
+    with pytest.raises(SystemExit):
+        cli.main(["test", "--config"])                                 # dangling flag
+    with pytest.raises(SystemExit):
+        cli.main(["fit"])
+
+
 def test_rotations_follow_numpy_global_rng():
     import scipy.stats
     import methods.iterative as it

@@ -307,6 +307,37 @@ def test_out_of_gamut_and_toe_values(lin):
     assert (out == 0).any() or (out == 1).any()     # the clip fired somewhere
 
 
+def test_dtype_rules_vs_reference(golden_dir, lin):
+    """Raw uint8 frames: Reinhard rescales (skimage img_as_float inside rgb2lab), Xiao / MK do not (methods/linear.py:45-124
+    never convert) -- fixtures from the reference called on uint8.  Mixed float32 / float64 arguments: float64 result."""
+    g = _g(golden_dir, "linear_dtypes.npz")
+    t8, r8 = g["t8"], g["r8"]
+    out = lin.color_transfer_in_correlated_color_space(t8, r8)
+    assert out.dtype == np.float64 and out.max() > 100                   # 0..255 scale
+    np.testing.assert_allclose(out, g["xiao_u8"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(lin.monge_kantorovitch_color_transfer(t8, r8), g["mk_u8"], rtol=0, atol=1e-7)
+    out = lin.color_transfer_between_images(t8, r8)
+    assert out.dtype == np.float64 and out.max() <= 1
+    np.testing.assert_allclose(out, g["reinhard_u8"], rtol=0, atol=1e-9)
+    t32, r64 = (t8 / 255).astype(np.float32), (r8 / 255).astype(np.float64)
+    out = lin.color_transfer_between_images(t32, r64)
+    assert out.dtype == g["reinhard_f32_f64"].dtype == np.float64
+    # the reference computed rgb2lab(target) in float32 here (its own 1e-4-level noise, SURVEY App. B): RGB within 1e-5
+    np.testing.assert_allclose(out, g["reinhard_f32_f64"], rtol=0, atol=1e-5)
+    out = lin.color_transfer_between_images(t32.astype(np.float64), r64.astype(np.float32))
+    assert out.dtype == g["reinhard_f64_f32"].dtype == np.float64
+    np.testing.assert_allclose(out, g["reinhard_f64_f32"], rtol=0, atol=1e-5)
+
+
+def test_idt_cuda_zero_iterations():
+    import methods.iterative as it
+    x = torch.rand(5, 7, 3, device="cuda")
+    out = it.iterative_distribution_transfer_cuda(x, x.flip(0), n_iter=0)
+    assert out.dtype == torch.float64 and torch.equal(out, x.double())
+    buf = torch.empty(5, 7, 3, dtype=torch.float64, device="cuda")
+    assert it.iterative_distribution_transfer_cuda(x, x.flip(0), rotations=np.zeros((0, 3, 3)), out=buf) is buf and torch.equal(buf, x.double())
+
+
 def test_empty_image(lin):
     out = lin.color_transfer_between_images(np.zeros((0, 4, 3), np.float32), np.ones((2, 2, 3), np.float32))
     assert out.shape == (0, 4, 3)
