@@ -6,10 +6,12 @@ driver launches one rank per GPU with torch.distributed.run.  Rank 0 prints ONE 
 
 Workload (BASELINE.json configs[1]): methods.linear.color_transfer_between_images (Reinhard) on
 synthetic 1920x1080 float32 RGB pairs, inputs resident in HBM, `--pairs` pairs per step
-(one step = one ct_reinhard_f32 call: stats sweep over 2*pairs images, finishing kernel,
-apply sweep).  Frames shard across ranks (frame f -> rank f % world); per-frame Lab stats
-(the per-frame metrics record) are gathered with ONE RCCL all_gather at the end of the timed
-region.  `value` = all ranks' pairs / max-over-ranks wall time.
+(one step = one ct_reinhard_f32 call -- statistics sweep over 2*pairs images, apply sweep with
+the statistics finished in its prologue -- plus the per-frame metric of Runner.test_step,
+ct_frame_psnr_f32 of the corrected frames against resident ground-truth frames; `--metrics
+psnr,ssim,icid` adds the other two).  Frames shard across ranks (frame f -> rank f % world);
+the [frames, n_metrics] table is gathered with ONE RCCL all_gather at the end of the timed
+region (configs[4]).  `value` = all ranks' pairs / max-over-ranks wall time.
 
 Extra keys: `roofline` (dominant kernel, HIP events per launch), `cpu_baseline` (the numpy oracle
 of the same function, rank 0, N=1 only), `extra` (MK / Xiao / IDT rates, informational).
@@ -38,14 +40,15 @@ HBM_PEAK = 8.0e12                            # B/s, MI355X_MICROARCH.md "HBM3E p
 
 
 def synth_frames(frame_ids, device):
-    """SURVEY 8d synthetic inputs: rng = default_rng(1234 + frame); uniform float32 HWC."""
+    """SURVEY 8d synthetic inputs: rng = default_rng(1234 + frame); uniform float32 HWC (target, reference, ground truth)."""
     t = np.empty((len(frame_ids), H, W, 3), dtype=np.float32)
-    r = np.empty_like(t)
+    r, g = np.empty_like(t), np.empty_like(t)
     for i, f in enumerate(frame_ids):
         rng = np.random.default_rng(1234 + f)
         t[i] = rng.random((H, W, 3), dtype=np.float32)
         r[i] = rng.random((H, W, 3), dtype=np.float32)
-    return torch.from_numpy(t).to(device), torch.from_numpy(r).to(device)
+        g[i] = rng.random((H, W, 3), dtype=np.float32)
+    return torch.from_numpy(t).to(device), torch.from_numpy(r).to(device), torch.from_numpy(g).to(device)
 
 
 def cpu_baseline(n_pairs=4):
@@ -72,6 +75,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--pairs", type=int, default=4, help="stereopairs per step per GPU")
+    ap.add_argument("--metrics", default="psnr", help="per-frame metrics inside the timed region: psnr[,ssim,icid] or none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
@@ -93,12 +97,25 @@ def main():
     ct_hip.lib()                                   # fail loudly if the HIP library is missing
 
     B, K, Wm = args.pairs, args.steps, args.warmup
+    names = [m for m in args.metrics.split(",") if m and m != "none"]
+    assert all(m in ("psnr", "ssim", "icid") for m in names), names
     # frames owned by this rank: f % world == rank; a ring of `B` resident pairs is re-used every step
     frame_ids = [rank + world * i for i in range(B)]
-    tgt, ref = synth_frames(frame_ids, device)
+    tgt, ref, gt = synth_frames(frame_ids, device)
     out = torch.empty_like(tgt)
-    metrics = torch.zeros((K, 2 * B, ct_hip.CT_LAB_STATS_STRIDE), dtype=torch.float64, device=device)
+    gt_nchw = gt.permute(0, 3, 1, 2).contiguous() if ("ssim" in names or "icid" in names) else None
+    n_m = max(len(names), 1)
+    metrics = torch.zeros((K, B, n_m), dtype=torch.float64, device=device)      # this rank's [frames, n_metrics] table
     gathered = torch.empty((world,) + tuple(metrics.shape), dtype=torch.float64, device=device) if world > 1 else None
+
+    def step(i):
+        ct_hip.reinhard(tgt, ref, out=out)
+        for j, m in enumerate(names):
+            if m == "psnr":
+                metrics[i, :, j] = ct_hip.frame_psnr(out, gt)[:, 1]            # layout-agnostic: HWC against HWC
+            else:
+                o = out.permute(0, 3, 1, 2).contiguous()
+                metrics[i, :, j] = (ct_hip.frame_ssim if m == "ssim" else ct_hip.frame_icid)(o, gt_nchw)
 
     def barrier():
         if world > 1:
@@ -106,13 +123,13 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(Wm):
-        ct_hip.reinhard(tgt, ref, out=out, stats_out=metrics[0])
+        step(0)
     if world > 1:                                   # warm the communicator outside the timed region
         dist.all_gather_into_tensor(gathered, metrics)
     barrier()
     t0 = time.perf_counter()
     for i in range(K):
-        ct_hip.reinhard(tgt, ref, out=out, stats_out=metrics[i])
+        step(i)
     if world > 1:
         dist.all_gather_into_tensor(gathered, metrics)      # the per-frame metric gather (RCCL over xGMI)
     barrier()
@@ -138,36 +155,39 @@ def main():
         torch.cuda.synchronize()
         ct_hip.profile_events(ev)
         for i in range(n_prof):
-            ct_hip.reinhard(tgt, ref, out=out, stats_out=metrics[0])
+            ct_hip.reinhard(tgt, ref, out=out)
             torch.cuda.synchronize()
             ts.append(ev[0].elapsed_time(ev[1]) * 1e-3)
             ta.append(ev[2].elapsed_time(ev[3]) * 1e-3)
         ct_hip.profile_events(None)
         t_stats, t_apply = float(np.mean(ts)), float(np.mean(ta))
-        kern = {
-            "moments_kernel<float,true>": {"bytes": 2 * B * PLANE_F32, "t": t_stats},
-            "reinhard_apply_kernel<float,false>": {"bytes": 2 * B * PLANE_F32, "t": t_apply},
-        }
+        table = ct_hip.lab_mode() == "table"
+        k_stats = "lab_moments_lut_kernel" if table else "moments_kernel<float,true>"
+        k_apply = "reinhard_apply_lut_kernel<false>" if table else "reinhard_apply_kernel<float,false>"
+        kern = {k_stats: {"bytes": 2 * B * PLANE_F32, "t": t_stats},      # reads the 2B images once
+                k_apply: {"bytes": 2 * B * PLANE_F32, "t": t_apply}}      # reads B targets, writes B outputs
         dom = max(kern, key=lambda k: kern[k]["t"])
         ach = kern[dom]["bytes"] / kern[dom]["t"]
         # HBM traffic per launch of the dominant kernel from the committed PMC profile (separate --pmc passes,
         # FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md "HBM"), valid for the same pairs-per-step only
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get("pairs_per_step") == B:
-                traffic = tj.get("moments_kernel_hbm_bytes_per_launch")
+            if tj.get("pairs_per_step") == B and tj.get("lab_mode") == ct_hip.lab_mode():
+                traffic = tj.get("hbm_bytes_per_launch", {}).get(dom)
         roof = {"bound": "hbm", "kernel": dom, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": ach / HBM_PEAK, "traffic": traffic,
-                "limiter": "VALU issue rate, not HBM: the float64-exact sRGB<->Lab arithmetic needs ~119 (stats) / ~205 "
-                           "(apply) VALU instructions per pixel at >= 4 cycles each (DESIGN.md 4.1); HBM traffic == algorithmic bytes",
+                "limiter": "vector-instruction issue, HBM and LDS look-ups each sit at 35-40 us of this ~50 us launch and overlap "
+                           "imperfectly (DESIGN.md 4.1); HBM traffic == algorithmic bytes",
                 "algorithmic_bytes_per_launch": kern[dom]["bytes"], "avg_launch_s": kern[dom]["t"],
+                "lab_arithmetic": ct_hip.lab_mode(),
                 "kernels": {k: {"GB/s": v["bytes"] / v["t"] / 1e9, "avg_launch_us": v["t"] * 1e6,
                                 "algorithmic_bytes_per_launch": v["bytes"]} for k, v in kern.items()},
                 "path": {"algorithmic_bytes_per_pair": ALGO_BYTES_PER_PAIR,
                          "GB/s": ALGO_BYTES_PER_PAIR * value / world / 1e9,
-                         "frac_of_peak": ALGO_BYTES_PER_PAIR * value / world / HBM_PEAK}}
+                         "frac_of_peak": ALGO_BYTES_PER_PAIR * value / world / HBM_PEAK,
+                         "note": "value includes the per-frame metric kernels (%s) in the timed region" % (",".join(names) or "none")}}
 
         if not args.no_extra and world == 1:        # informational rates of the other paths: single-GPU runs only
             def rate(fn, n=10):
@@ -178,6 +198,12 @@ def main():
                     fn()
                 torch.cuda.synchronize()
                 return n / (time.perf_counter() - t0)
+            extra["reinhard_pairs_per_s_transfer_only"] = B * rate(lambda: ct_hip.reinhard(tgt, ref, out=out), n=200)
+            o_nchw, g_nchw = out.permute(0, 3, 1, 2).contiguous(), gt.permute(0, 3, 1, 2).contiguous()
+            extra["frames_per_s_psnr"] = B * rate(lambda: ct_hip.frame_psnr(out, gt), n=100)
+            extra["frames_per_s_ssim"] = B * rate(lambda: ct_hip.frame_ssim(o_nchw, g_nchw), n=100)
+            extra["frames_per_s_icid"] = B * rate(lambda: ct_hip.frame_icid(o_nchw, g_nchw), n=100)
+            del o_nchw, g_nchw
             extra["mk_pairs_per_s_f64out_hostalgebra"] = rate(
                 lambda: lin.monge_kantorovitch_color_transfer_cuda(tgt[0], ref[0], host_algebra=True))
             mk_out = torch.empty(tgt.shape, dtype=torch.float32, device=device)
@@ -238,9 +264,12 @@ def main():
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[1]: methods.linear.color_transfer_between_images (Reinhard) on "
-                                   "1920x1080 synthetic float32 RGB pairs, HBM-resident, float64 arithmetic",
+                                   "1920x1080 synthetic float32 RGB pairs, HBM-resident; apply sweep float64-grade, "
+                                   "statistics sweep float32 (the reference's own precision for float32 frames); "
+                                   "+ per-frame %s against resident ground truth" % (",".join(names) or "no metric"),
                        "pairs_per_step_per_gpu": B, "io_dtype": "float32", "height": H, "width": W,
-                       "sharding": "frame f -> rank f % world; one all_gather of per-frame Lab stats"},
+                       "lab_arithmetic": ct_hip.lab_mode(), "metrics": names,
+                       "sharding": "frame f -> rank f % world; one all_gather of the [frames, n_metrics] table"},
             "roofline": roof, "cpu_baseline": cpu, "extra": extra,
         }
         print(json.dumps(line), flush=True)

@@ -47,6 +47,9 @@ SIGNATURES = {
     "ct_mk_f32_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_int, _c_p, _c_sz, _c_p]),
     "ct_mk_f64_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_int, _c_p, _c_sz, _c_p]),
     "ct_frame_psnr_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
+    "ct_metric_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
+    "ct_frame_ssim_f32": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_sz, _c_p]),
+    "ct_frame_icid_f32": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_sz, _c_p]),
     "ct_mk_coef_f64": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_p, _c_p]),
     "ct_affine3x3_f32_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_p]),
     "ct_affine3x3_f64_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_p]),
@@ -274,6 +277,27 @@ def frame_psnr(a, b):
     ws = workspace(CT_WS_LAB_STATS, n, B, a.device)
     check(lib().ct_frame_psnr_f32(_ptr(a), _ptr(b), n, B, _ptr(out), _ptr(ws), ws.numel(), _stream()))
     return out
+
+
+def _frame_metric(name, a, b):
+    _require_cuda(a, b)
+    if a.shape != b.shape or a.dim() != 4 or a.shape[1] != 3 or a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise CtHipError("%s needs two float32 [B,3,H,W] tensors of one shape" % name)
+    B, _, h, w = a.shape
+    out = torch.empty((B,), dtype=torch.float64, device=a.device)
+    ws = workspace(CT_WS_LAB_STATS, 0, B, a.device, need=lib().ct_metric_workspace_bytes(h, w, B))
+    check(getattr(lib(), name)(_ptr(a), _ptr(b), h, w, B, _ptr(out), _ptr(ws), ws.numel(), _stream()))
+    return out
+
+
+def frame_ssim(a, b):
+    """Per-frame piq.ssim(a, b) (defaults, data range 1) of float32 [B,3,H,W] batches -> float64 [B] (methods/__init__.py:33)."""
+    return _frame_metric("ct_frame_ssim_f32", a, b)
+
+
+def frame_icid(a, b):
+    """Per-frame utils.icid.icid(a, b) (perceptual intent) of float32 [B,3,H,W] batches -> float64 [B] (methods/__init__.py:35)."""
+    return _frame_metric("ct_frame_icid_f32", a, b)
 
 
 def mk_coef(stats_t, stats_r, decomposition="MK"):

@@ -2,8 +2,9 @@
 
 `Runner(func_spec)` resolves a dotted path "pkg.mod.func" with importlib exactly like the reference
 (methods/__init__.py:14-16); `forward(batch)` applies it to every sample of the batch
-(methods/__init__.py:18-27) and `test_step` clamps and scores the result (methods/__init__.py:29-40;
-PSNR here -- SSIM/FSIM/iCID are third-party `piq`/`kornia` code).
+(methods/__init__.py:18-27) and `test_step` clamps and scores the result (methods/__init__.py:29-40):
+PSNR, SSIM and iCID per frame on the GPU (ct_frame_*_f32; piq / kornia / torchvision arithmetic restated, see
+oracle/metrics.py).  FSIM (piq's FFT-based phase congruency) is not implemented.
 
 If the resolved module also offers a device-resident variant `<func>_cuda`, the batch never leaves
 the GPU; otherwise the numpy callable is used through the same host round trip as the reference.
@@ -21,6 +22,22 @@ def psnr(x, y, data_range=1.0):
         return ct_hip.frame_psnr(x.float().contiguous(), y.float().contiguous())[:, 1]
     mse = ((x.double() - y.double()) ** 2).flatten(1).mean(dim=1)
     return 10.0 * torch.log10(data_range ** 2 / mse.clamp_min(1e-300))
+
+
+def ssim(x, y):
+    """piq.ssim(x, y) with piq's defaults, per sample [B] (GPU only: ct_frame_ssim_f32)."""
+    import ct_hip
+    return ct_hip.frame_ssim(x.float().contiguous(), y.float().contiguous())
+
+
+def icid(x, y):
+    """utils.icid.icid(x, y) (perceptual intent), per sample [B] (GPU only: ct_frame_icid_f32).  The reference returns
+    the mean over the batch; test loaders use batch size 1 (utils/data.py:168-179), where the two coincide."""
+    import ct_hip
+    return ct_hip.frame_icid(x.float().contiguous(), y.float().contiguous())
+
+
+METRICS = ("Test PSNR", "Test SSIM", "Test iCID")
 
 
 class Runner(torch.nn.Module):
@@ -51,4 +68,8 @@ class Runner(torch.nn.Module):
 
     def test_step(self, batch, batch_idx=0, dataloader_idx=0):
         result = self(batch).clamp(0, 1)
-        return {"Test PSNR": psnr(result, batch["gt"].to(result.device))}
+        gt = batch["gt"].to(result.device)
+        out = {"Test PSNR": psnr(result, gt)}
+        if result.is_cuda:
+            out["Test SSIM"], out["Test iCID"] = ssim(result, gt), icid(result, gt)
+        return out

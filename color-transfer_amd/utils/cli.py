@@ -4,7 +4,8 @@ A minimal look-alike of the reference's LightningCLI entry point (utils/cli.py:1
 `test` sub-command only (Lightning/jsonargparse are not part of this stack): YAML with `class_path/init_args`
 for model and data, dotted `--section.key value` overrides, `trainer.*` keys accepted and ignored.  Frames are
 sharded over ranks when launched with torch.distributed.run (frame f -> rank f % world) and the per-frame
-metrics are gathered with ONE collective (utils/sharding.py); rank 0 prints the reference's `Test PSNR`.
+metrics (PSNR, SSIM, iCID: the reference's Test PSNR / Test SSIM / Test iCID) are gathered with ONE collective
+(utils/sharding.py); rank 0 prints their means.
 """
 import importlib
 import os
@@ -71,19 +72,23 @@ def main(argv=None):
     data_cfg["class_path"] = "utils.data.DataModule"
     frames = _instantiate(data_cfg).test_frames()
     mine = sh.frames_of_rank(len(frames), rank, world)
+    from methods import METRICS, icid, psnr, ssim
     rows = []
     for f in mine:
         batch = {k: v.unsqueeze(0).to(device) for k, v in frames[f].items()}
         if hasattr(model, "test_step"):
-            rows.append(model.test_step(batch, f)["Test PSNR"].reshape(1))
+            m = model.test_step(batch, f)
+            rows.append(torch.stack([m[k].reshape(()) for k in METRICS]))
         else:                                   # CNN modules: forward(target, reference, inference=True)
-            from methods import psnr
             corrected, _ = model(batch["target"], batch["reference"], inference=True)
-            rows.append(psnr(corrected, batch["gt"]).reshape(1))
-    local = torch.stack(rows).double() if rows else torch.zeros((0, 1), dtype=torch.float64, device=device)
-    table = sh.gather_frame_metrics(local, len(frames), rank, world)
+            corrected = corrected.clamp(0, 1)
+            rows.append(torch.stack([fn(corrected, batch["gt"]).reshape(()) for fn in (psnr, ssim, icid)]))
+    local = torch.stack(rows).double() if rows else torch.zeros((0, len(METRICS)), dtype=torch.float64, device=device)
+    table = sh.gather_frame_metrics(local, len(frames), rank, world)        # [n_frames, 3]: PSNR, SSIM, iCID per frame
     if rank == 0:
-        print("Test PSNR: %.4f  (%d frames, %d GPU%s)" % (float(table.mean()), len(frames), world, "" if world == 1 else "s"))
+        for i, name in enumerate(METRICS):
+            print("%s: %.4f" % (name, float(table[:, i].mean())), end="   " if i + 1 < len(METRICS) else "")
+        print("  (%d frames, %d GPU%s)" % (len(frames), world, "" if world == 1 else "s"))
     if world > 1:
         dist.destroy_process_group()
     return table

@@ -140,6 +140,21 @@ int ct_affine3x3_f32_f32(const float *in, const double *coef, float *out, int64_
 int ct_frame_psnr_f32(const float *a, const float *b, int64_t n_elems, int batch, double *out, void *ws,
                       size_t ws_bytes, void *stream);
 
+/* ---- per-frame SSIM and iCID, the other metrics of Runner.test_step (methods/__init__.py:33,35) --------------------------
+ * a (result, already clamped to [0,1] by the caller like methods/__init__.py:30), b (ground truth): [batch][3][height][width]
+ * float32, NCHW planes; out[i] = the metric of frame i.
+ *   ct_frame_ssim_f32  piq.ssim defaults: average-pool by f = max(1, round(min(H,W)/256)), 11x11 Gaussian (sigma 1.5) on
+ *                      "valid" windows, k1 0.01, k2 0.03, mean over channels and positions; needs min(H,W)/f >= 11
+ *   ct_frame_icid_f32  utils/icid.py:28-152 (intent "perceptual", all seven maps, downsampling on): bilinear resize by 1/f,
+ *                      Lab, eleven 11x11 sigma-2 Gaussian moments with reflect padding, 1 - mean(product of the maps)
+ * One fused tile kernel per metric + a fixed-order finishing kernel; float32 arithmetic like the reference's torch code,
+ * float64 sums.  ws: ct_metric_workspace_bytes(height, width, batch).                                                  */
+size_t ct_metric_workspace_bytes(int height, int width, int batch);
+int ct_frame_ssim_f32(const float *a, const float *b, int height, int width, int batch, double *out, void *ws,
+                      size_t ws_bytes, void *stream);
+int ct_frame_icid_f32(const float *a, const float *b, int height, int width, int batch, double *out, void *ws,
+                      size_t ws_bytes, void *stream);
+
 /* ---- a4: methods.iterative.iterative_distribution_transfer (methods/iterative.py:8-59) ----
  * Per iteration: projection on the rotated axes (float64, fma chain), exact lo/hi, 2x3 histograms
  * with numpy's bin rule (LDS-binned integer atomics), cumulative LUT, np.interp apply with the

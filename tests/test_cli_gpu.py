@@ -17,14 +17,15 @@ def test_cli_test_others(spec, capsys):
     from utils import cli
     table = cli.main(["test", "--config", os.path.join(CFG, "others.yaml"), "--model.func_spec", spec,
                       "--data.n_frames", "3", "--data.height", "64", "--data.width", "96", "--trainer.logger", "false"])
-    assert table.shape == (3, 1) and torch.isfinite(table).all()
+    assert table.shape == (3, 3) and torch.isfinite(table).all()      # PSNR, SSIM, iCID per frame
     assert "Test PSNR" in capsys.readouterr().out
     # the transfer must improve on doing nothing for this synthetic distortion
     from utils.data import SyntheticStereoFrames
     from methods import psnr
     fr = SyntheticStereoFrames(3, 64, 96)
     base = torch.stack([psnr(fr[i]["target"][None], fr[i]["gt"][None]) for i in range(3)]).mean()
-    assert float(table.mean()) > float(base)
+    assert float(table[:, 0].mean()) > float(base)
+    assert 0 < float(table[:, 1].mean()) <= 1 and 0 <= float(table[:, 2].mean()) < 1
 
 
 def test_runner_numpy_path_equals_cuda_path():
@@ -44,7 +45,7 @@ def test_cli_dcmcs3di(capsys):
     from utils import cli
     table = cli.main(["test", "--config", os.path.join(CFG, "dcmcs3di.yaml"), "--model.extraction_layers", "2",
                       "--model.transfer_layers", "1", "--data.n_frames", "2", "--data.height", "32", "--data.width", "64"])
-    assert table.shape == (2, 1) and torch.isfinite(table).all()
+    assert table.shape == (2, 3) and torch.isfinite(table).all()
 
 
 def test_frame_psnr_kernel():

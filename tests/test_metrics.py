@@ -1,0 +1,115 @@
+"""Per-frame quality metrics (Runner.test_step, reference methods/__init__.py:29-40).
+
+not-gpu: the oracle (oracle/metrics.py) against its anchors -- scikit-image's structural_similarity for the SSIM core
+(tests/golden/ssim_anchor.npz) and a run of the reference's own utils/icid.py for iCID (tests/golden/icid.npz);
+gpu: the HIP kernels (ct_frame_ssim_f32 / ct_frame_icid_f32 / ct_frame_psnr_f32, through the C ABI) against the oracle and
+the fixtures, with and without downsampling, plus size-independent properties at 1080p."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+from oracle import metrics as om     # noqa: E402
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def _u8(a):
+    return torch.from_numpy(a.astype(np.float32) / np.float32(255))
+
+
+def test_oracle_ssim_vs_skimage_anchor(golden_dir):
+    g = _g(golden_dir, "ssim_anchor.npz")
+    for tag in ("a", "b", "c"):
+        x, y = torch.from_numpy(g[tag + "/x"])[None], torch.from_numpy(g[tag + "/y"])[None]
+        assert abs(float(om.ssim(x, y)[0]) - float(g[tag + "/ssim"])) < 1e-9, tag
+    x = torch.rand(2, 3, 40, 50)
+    assert torch.allclose(om.ssim(x, x), torch.ones(2, dtype=torch.float64), atol=1e-12)
+    assert om.metric_factor(1080, 1920) == 4 and om.metric_factor(383, 999) == 1 and om.metric_factor(384, 999) == 2
+    assert om.metric_factor(640, 640) == 2 and om.metric_factor(650, 700) == 3      # round half to even: 2.5 -> 2
+
+
+def test_oracle_icid_vs_reference_run(golden_dir):
+    g = _g(golden_dir, "icid.npz")
+    for tag in ("a", "b", "c", "d"):
+        x, y = _u8(g[tag + "/x_u8"]), _u8(g[tag + "/y_u8"])
+        got = float(om.icid(x, y))
+        assert abs(got - float(g[tag + "/icid_f64"])) < 1e-10, tag           # float64 run of the reference
+        assert abs(got - float(g[tag + "/icid_f32"])) < 5e-6, tag            # the reference as it runs (float32)
+        assert float(om.icid(x, x)) == 0.0 == float(g[tag + "/icid_same"])
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def hip():
+    import ct_hip
+    ct_hip.lib()
+    return ct_hip
+
+
+def _pair(seed, b, h, w, noise=0.05):
+    gen = torch.Generator().manual_seed(seed)
+    base = torch.rand(b, 3, h // 8 + 2, w // 8 + 2, generator=gen)
+    gt = torch.nn.functional.interpolate(base, size=(h, w), mode="bicubic", align_corners=True).clamp(0, 1)
+    gt = (gt + 0.04 * torch.rand(b, 3, h, w, generator=gen)).clamp(0, 1)
+    x = (gt ** 1.15 * 0.93 + 0.02 + noise * torch.randn(b, 3, h, w, generator=gen)).clamp(0, 1)
+    return x.contiguous(), gt.contiguous()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 40, 56), (1, 11, 11), (1, 97, 130), (3, 400, 520), (1, 650, 700), (1, 1080, 1920), (1, 1083, 1925)])
+def test_hip_ssim_vs_oracle(hip, shape):
+    b, h, w = shape
+    x, y = _pair(h + w, b, h, w)
+    got = hip.frame_ssim(x.cuda(), y.cuda()).cpu()
+    want = om.ssim(x, y)
+    assert got.shape == (b,) and torch.allclose(got, want, rtol=0, atol=2e-6), (got, want)
+    assert torch.allclose(hip.frame_ssim(x.cuda(), x.cuda()).cpu(), torch.ones(b, dtype=torch.float64), atol=1e-6)
+    assert torch.equal(got, hip.frame_ssim(x.cuda(), y.cuda()).cpu())          # deterministic
+
+
+@pytest.mark.gpu
+def test_hip_ssim_vs_skimage_anchor(hip, golden_dir):
+    g = _g(golden_dir, "ssim_anchor.npz")
+    for tag in ("a", "b", "c"):
+        x, y = torch.from_numpy(g[tag + "/x"])[None].cuda(), torch.from_numpy(g[tag + "/y"])[None].cuda()
+        assert abs(float(hip.frame_ssim(x, y)[0]) - float(g[tag + "/ssim"])) < 2e-6, tag
+
+
+@pytest.mark.gpu
+def test_hip_icid_vs_reference_run(hip, golden_dir):
+    g = _g(golden_dir, "icid.npz")
+    for tag in ("a", "b", "c", "d"):
+        x, y = _u8(g[tag + "/x_u8"]).cuda(), _u8(g[tag + "/y_u8"]).cuda()
+        got = float(hip.frame_icid(x, y)[0])
+        assert abs(got - float(g[tag + "/icid_f64"])) < 5e-6, (tag, got, float(g[tag + "/icid_f64"]))
+        assert abs(float(hip.frame_icid(x, x)[0])) < 1e-6            # float32 maps: products of ones within rounding
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 37, 53), (1, 6, 6), (3, 270, 480), (1, 1080, 1920), (1, 1083, 1925)])
+def test_hip_icid_vs_oracle(hip, shape):
+    b, h, w = shape
+    x, y = _pair(h * 3 + w, b, h, w)
+    got = hip.frame_icid(x.cuda(), y.cuda()).cpu()
+    want = torch.stack([om.icid(x[i:i + 1], y[i:i + 1]) for i in range(b)])
+    assert torch.allclose(got, want, rtol=0, atol=5e-6), (got, want)
+    assert torch.equal(got, hip.frame_icid(x.cuda(), y.cuda()).cpu())
+
+
+@pytest.mark.gpu
+def test_runner_test_step_reports_all_metrics(hip):
+    from methods import METRICS, Runner
+    x, y = _pair(9, 2, 64, 96)
+    r = Runner("methods.linear.color_transfer_between_images")
+    m = r.test_step({"target": x.cuda(), "reference": y.flip(3).contiguous().cuda(), "gt": y.cuda()})
+    assert tuple(m.keys()) == METRICS and all(v.shape == (2,) and torch.isfinite(v).all() for v in m.values())
+    res = r({"target": x.cuda(), "reference": y.flip(3).contiguous().cuda()}).clamp(0, 1).cpu()
+    assert torch.allclose(m["Test PSNR"].cpu(), om.psnr(res, y), atol=1e-9)
+    assert torch.allclose(m["Test SSIM"].cpu(), om.ssim(res, y), atol=2e-6)
+    assert abs(float(m["Test iCID"][1]) - float(om.icid(res[1:2], y[1:2]))) < 5e-6
+    with pytest.raises(hip.CtHipError):
+        hip.frame_ssim(torch.rand(1, 3, 8, 8).cuda(), torch.rand(1, 3, 8, 8).cuda())      # smaller than the 11x11 window
