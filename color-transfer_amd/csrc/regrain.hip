@@ -1,0 +1,234 @@
+// regrain.hip -- the "regrain" post-process of automated_color_grading (reference methods/iterative.py:62-138) on gfx950.
+//
+//   _regrain  (iterative.py:62-78)   multigrid recursion: both images are halved with skimage.transform.resize down to
+//                                    ~20 pixels, the coarse solution is resized back up and relaxed on every level
+//   _solve    (iterative.py:81-117)  nbit Jacobi sweeps of a 5-point gradient-preserving relaxation (psi / phi weights
+//                                    from the gradients of the ORIGINAL image)
+//   skimage.transform.resize (third party, scikit-image 0.18.3 _warps.py:resize/warp + scipy.ndimage.gaussian_filter):
+//       down: Gaussian anti-aliasing, sigma = (factor - 1) / 2 per axis, radius int(4 sigma + 0.5), 'mirror' boundary,
+//             axis 0 then axis 1; then bilinear sampling at factor * (i + 0.5) - 0.5 with 'reflect' boundary
+//       up:   the bilinear sampling alone
+//
+// All arithmetic is float64 (the reference's `img_arr_col` is the float64 IDT output; a float32 target is promoted here
+// where the reference resizes it in float32 -- a 1e-7-level difference, see tests).  HWC layout, one thread per pixel;
+// every launch is a plain streaming / 5-point stencil sweep (HBM bound; 244 launches for a 1080p frame).
+#include "ct_common.h"
+
+namespace ct {
+
+constexpr int kRgMaxLevels = 8;
+
+__device__ __forceinline__ int mirror_idx(int i, int n) {          // scipy.ndimage 'mirror': d c b | a b c d | c b a
+    if (n == 1) return 0;
+    i = i < 0 ? -i : i;
+    const int p = 2 * (n - 1);
+    i %= p;
+    return i >= n ? p - i : i;
+}
+
+// skimage _warp_fast coord_map(dim, coord, 'R')
+__device__ __forceinline__ int reflect_idx(int coord, int dim) {
+    const int cmax = dim - 1;
+    if (dim == 1) return 0;
+    if (coord < 0) {
+        const int n = -coord;
+        return ((n / cmax) % 2 != 0) ? cmax - (n % cmax) : n % cmax;
+    }
+    if (coord > cmax) return ((coord / cmax) % 2 != 0) ? cmax - (coord % cmax) : coord % cmax;
+    return coord;
+}
+
+// one axis of scipy.ndimage.gaussian_filter on an [H][W][3] image: out = sum_k w[k] in[mirror(i + k - r)]
+__global__ __launch_bounds__(kBlock) void rg_gauss_kernel(const double *__restrict__ in, double *__restrict__ out, int H, int W, int axis,
+                                                         int radius, const double w0, const double w1, const double w2) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (int64_t)H * W) return;
+    const int r = (int)(i / W), c = (int)(i % W);
+    const double wk[3] = {w0, w1, w2};                      // symmetric kernel: w[|k|], radius <= 2
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int k = -radius; k <= radius; ++k) {
+        const int rr = axis == 0 ? mirror_idx(r + k, H) : r, cc = axis == 1 ? mirror_idx(c + k, W) : c;
+        const double *p = in + ((size_t)rr * W + cc) * 3;
+        const double g = wk[k < 0 ? -k : k];
+        acc[0] += g * p[0]; acc[1] += g * p[1]; acc[2] += g * p[2];
+    }
+    double *o = out + (size_t)i * 3;
+    o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
+}
+
+// skimage warp(order=1, mode='reflect') of an [Hi][Wi][3] image to [Ho][Wo][3]: source = factor * (i + 0.5) - 0.5
+__global__ __launch_bounds__(kBlock) void rg_bilinear_kernel(const double *__restrict__ in, double *__restrict__ out, int Hi, int Wi, int Ho,
+                                                            int Wo, double fr, double fc) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (int64_t)Ho * Wo) return;
+    const int r = (int)(i / Wo), c = (int)(i % Wo);
+    const double sr = fr * ((double)r + 0.5) - 0.5, sc = fc * ((double)c + 0.5) - 0.5;
+    const int minr = (int)floor(sr), minc = (int)floor(sc), maxr = (int)ceil(sr), maxc = (int)ceil(sc);
+    const double dr = sr - (double)minr, dc = sc - (double)minc;
+    const int r0 = reflect_idx(minr, Hi), r1 = reflect_idx(maxr, Hi), c0 = reflect_idx(minc, Wi), c1 = reflect_idx(maxc, Wi);
+    const double *p00 = in + ((size_t)r0 * Wi + c0) * 3, *p01 = in + ((size_t)r0 * Wi + c1) * 3;
+    const double *p10 = in + ((size_t)r1 * Wi + c0) * 3, *p11 = in + ((size_t)r1 * Wi + c1) * 3;
+    double *o = out + (size_t)i * 3;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const double top = (1.0 - dc) * p00[ch] + dc * p01[ch];
+        const double bottom = (1.0 - dc) * p10[ch] + dc * p11[ch];
+        o[ch] = (1.0 - dr) * top + dr * bottom;
+    }
+}
+
+// iterative.py:91-98: gradient magnitude of the original image -> psi, phi  (wt[i] = {psi, phi})
+__global__ __launch_bounds__(kBlock) void rg_weights_kernel(const double *__restrict__ in, double2 *__restrict__ wt, int H, int W, double phi_scale) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (int64_t)H * W) return;
+    const int r = (int)(i / W), c = (int)(i % W);
+    const double *pr = in + ((size_t)r * W + min(c + 1, W - 1)) * 3, *pl = in + ((size_t)r * W + max(c - 1, 0)) * 3;
+    const double *pd = in + ((size_t)min(r + 1, H - 1) * W + c) * 3, *pu = in + ((size_t)max(r - 1, 0) * W + c) * 3;
+    double s = 0.0;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const double dx = pr[ch] - pl[ch], dy = pd[ch] - pu[ch];
+        s += dx * dx + dy * dy;
+    }
+    const double delta = sqrt(s);
+    double psi = 256.0 * delta / 5.0;
+    psi = psi > 1.0 ? 1.0 : psi;
+    wt[i] = make_double2(psi, phi_scale / (1.0 + 10.0 * delta));
+}
+
+// one sweep of iterative.py:106-115 (Jacobi: everything on the right-hand side is the previous iterate)
+__global__ __launch_bounds__(kBlock) void rg_sweep_kernel(const double *__restrict__ prev, const double *__restrict__ in, const double *__restrict__ col,
+                                                         const double2 *__restrict__ wt, double *__restrict__ next, int H, int W) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (int64_t)H * W) return;
+    const int r = (int)(i / W), c = (int)(i % W);
+    const size_t iR = (size_t)r * W + min(c + 1, W - 1), iL = (size_t)r * W + max(c - 1, 0);
+    const size_t iD = (size_t)min(r + 1, H - 1) * W + c, iU = (size_t)max(r - 1, 0) * W + c;
+    const double2 w0 = wt[i];
+    const double psi = w0.x, phi = w0.y;
+    const double phi1 = (wt[iR].y + phi) / 2, phi2 = (wt[iD].y + phi) / 2, phi3 = (wt[iL].y + phi) / 2, phi4 = (wt[iU].y + phi) / 2;
+    const double den = psi + phi1 + phi2 + phi3 + phi4;
+    const double eps = 1e-6, rho = 1 / 5.0;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const double x = in[i * 3 + ch];
+        const double num = psi * col[i * 3 + ch] + phi1 * (prev[iR * 3 + ch] - in[iR * 3 + ch] + x) + phi2 * (prev[iD * 3 + ch] - in[iD * 3 + ch] + x) +
+                           phi3 * (prev[iL * 3 + ch] - in[iL * 3 + ch] + x) + phi4 * (prev[iU * 3 + ch] - in[iU * 3 + ch] + x);
+        next[i * 3 + ch] = num / (den + eps) * (1 - rho) + rho * prev[i * 3 + ch];
+    }
+}
+
+struct RgLevel { int h, w; };
+
+static int rg_levels(int H, int W, int n_nbits, RgLevel *lv) {      // iterative.py:62-68: recurse while len(nbits) > 1 and h2 > 20 and w2 > 20
+    int n = 0;
+    lv[n++] = {H, W};
+    while (n < n_nbits) {
+        const int h2 = (lv[n - 1].h + 1) / 2, w2 = (lv[n - 1].w + 1) / 2;
+        if (!(h2 > 20 && w2 > 20)) break;
+        lv[n++] = {h2, w2};
+    }
+    return n;
+}
+
+static inline dim3 rg_grid(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+
+// skimage.transform.resize(src [hi][wi][3] -> dst [ho][wo][3]); tmp: two [hi][wi][3] buffers (down-scaling only)
+static int rg_resize(const double *src, int hi, int wi, double *dst, int ho, int wo, double *tmp0, double *tmp1, hipStream_t s) {
+    const double fr = (double)hi / (double)ho, fc = (double)wi / (double)wo;
+    const double *cur = src;
+    double *bufs[2] = {tmp0, tmp1};
+    int nb = 0;
+    for (int axis = 0; axis < 2; ++axis) {
+        const double f = axis == 0 ? fr : fc;
+        const double sigma = f > 1.0 ? (f - 1.0) / 2.0 : 0.0;
+        if (!(sigma > 1e-15)) continue;                               // scipy skips such axes
+        const int radius = (int)(4.0 * sigma + 0.5);
+        if (radius > 2) return CT_E_BADARG;                           // halving pyramids never get here
+        double w[3] = {1.0, 0.0, 0.0}, sum = 0.0;
+        for (int k = -radius; k <= radius; ++k) sum += exp(-0.5 / (sigma * sigma) * (double)(k * k));
+        for (int k = 0; k <= radius; ++k) w[k] = exp(-0.5 / (sigma * sigma) * (double)(k * k)) / sum;
+        hipLaunchKernelGGL(rg_gauss_kernel, rg_grid((int64_t)hi * wi), dim3(kBlock), 0, s, cur, bufs[nb], hi, wi, axis, radius, w[0], w[1], w[2]);
+        CT_CHECK_LAUNCH();
+        cur = bufs[nb];
+        nb ^= 1;
+    }
+    hipLaunchKernelGGL(rg_bilinear_kernel, rg_grid((int64_t)ho * wo), dim3(kBlock), 0, s, cur, dst, hi, wi, ho, wo, fr, fc);
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+}
+
+}  // namespace ct
+
+extern "C" {
+
+size_t ct_regrain_workspace_bytes(int height, int width) {
+    if (height < 1 || width < 1) return 0;
+    ct::RgLevel lv[ct::kRgMaxLevels];
+    const int n = ct::rg_levels(height, width, 6, lv);
+    size_t doubles = (size_t)height * width * 3 * 2;                   // two resize scratch images at the finest size
+    for (int l = 0; l < n; ++l) doubles += (size_t)lv[l].h * lv[l].w * (3 * 4 + 2);   // in, col, two iterates, {psi, phi}
+    return doubles * sizeof(double) + 256;
+}
+
+// img_in, img_col, out: device [height][width][3] float64 (out may not alias the inputs); nbits: host array (the reference's
+// default is {4, 16, 32, 64, 64, 64}); one frame per call.
+int ct_regrain_f64(const double *img_in, const double *img_col, double *out, int height, int width, const int *nbits, int n_nbits,
+                   void *ws, size_t ws_bytes, void *stream) {
+    using namespace ct;
+    if (!img_in || !img_col || !out || !nbits || height < 1 || width < 1 || n_nbits < 1 || n_nbits > kRgMaxLevels) return CT_E_BADARG;
+    if (!ws || (reinterpret_cast<uintptr_t>(ws) & 15) || ws_bytes < ct_regrain_workspace_bytes(height, width)) return CT_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    RgLevel lv[kRgMaxLevels];
+    const int n = rg_levels(height, width, n_nbits, lv);
+    double *p = reinterpret_cast<double *>(ws);
+    double *tmp0 = p; p += (size_t)height * width * 3;
+    double *tmp1 = p; p += (size_t)height * width * 3;
+    const double *in_l[kRgMaxLevels], *col_l[kRgMaxLevels];
+    double *it_a[kRgMaxLevels], *it_b[kRgMaxLevels];
+    double2 *wt_l[kRgMaxLevels];
+    for (int l = 0; l < n; ++l) {
+        const size_t px = (size_t)lv[l].h * lv[l].w;
+        double *a = p; p += px * 3;
+        double *b = p; p += px * 3;
+        it_a[l] = p; p += px * 3;
+        it_b[l] = p; p += px * 3;
+        wt_l[l] = reinterpret_cast<double2 *>(p); p += px * 2;
+        if (l == 0) { in_l[0] = img_in; col_l[0] = img_col; }
+        else {
+            int rc = rg_resize(in_l[l - 1], lv[l - 1].h, lv[l - 1].w, a, lv[l].h, lv[l].w, tmp0, tmp1, s);
+            if (rc) return rc;
+            if ((rc = rg_resize(col_l[l - 1], lv[l - 1].h, lv[l - 1].w, b, lv[l].h, lv[l].w, tmp0, tmp1, s))) return rc;
+            in_l[l] = a; col_l[l] = b;
+        }
+    }
+    const double *coarse = nullptr;                                    // the solution of level l + 1
+    for (int l = n - 1; l >= 0; --l) {
+        const int h = lv[l].h, w = lv[l].w;
+        const int64_t px = (int64_t)h * w;
+        const double *start;
+        if (coarse == nullptr) start = in_l[l];                        // iterative.py:74: img_arr_out = img_arr_in
+        else {
+            const int rc = rg_resize(coarse, lv[l + 1].h, lv[l + 1].w, it_a[l], h, w, tmp0, tmp1, s);
+            if (rc) return rc;
+            start = it_a[l];
+        }
+        hipLaunchKernelGGL(rg_weights_kernel, rg_grid(px), dim3(kBlock), 0, s, in_l[l], wt_l[l], h, w, 30.0 * exp2(-(double)l));
+        CT_CHECK_LAUNCH();
+        const double *prev = start;
+        for (int i = 0; i < nbits[l]; ++i) {
+            // ping-pong; the LAST sweep of level 0 lands in the caller's buffer
+            double *next = (l == 0 && i == nbits[l] - 1) ? out : ((prev == it_b[l]) ? it_a[l] : it_b[l]);
+            hipLaunchKernelGGL(rg_sweep_kernel, rg_grid(px), dim3(kBlock), 0, s, prev, in_l[l], col_l[l], wt_l[l], next, h, w);
+            CT_CHECK_LAUNCH();
+            prev = next;
+        }
+        if (nbits[l] == 0 && l == 0) {                                 // no sweep on the finest level: the start image is the result
+            if (hipMemcpyAsync(out, prev, (size_t)px * 3 * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess) return (int)hipGetLastError();
+        }
+        coarse = prev;
+    }
+    return CT_OK;
+}
+
+}  // extern "C"

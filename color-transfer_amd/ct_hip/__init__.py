@@ -47,6 +47,8 @@ SIGNATURES = {
     "ct_mk_f32_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_int, _c_p, _c_sz, _c_p]),
     "ct_mk_f64_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_int, _c_p, _c_sz, _c_p]),
     "ct_frame_psnr_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
+    "ct_regrain_workspace_bytes": (_c_sz, [_c_int, _c_int]),
+    "ct_regrain_f64": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_p, _c_int, _c_p, _c_sz, _c_p]),
     "ct_metric_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
     "ct_frame_ssim_f32": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_sz, _c_p]),
     "ct_frame_icid_f32": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_sz, _c_p]),
@@ -276,6 +278,25 @@ def frame_psnr(a, b):
     out = torch.empty((B, 2), dtype=torch.float64, device=a.device)
     ws = workspace(CT_WS_LAB_STATS, n, B, a.device)
     check(lib().ct_frame_psnr_f32(_ptr(a), _ptr(b), n, B, _ptr(out), _ptr(ws), ws.numel(), _stream()))
+    return out
+
+
+def regrain(img_in, img_col, nbits=(4, 16, 32, 64, 64, 64), out=None):
+    """`_regrain(img_arr_in, img_arr_col, nbits)` of methods/iterative.py:62-117 on device tensors [H,W,3] (any float dtype;
+    computed in float64).  Returns float64 [H,W,3]."""
+    _require_cuda(img_in, img_col)
+    if img_in.dim() != 3 or img_in.shape[2] != 3 or img_in.shape != img_col.shape:
+        raise CtHipError("regrain needs two [H,W,3] tensors of one shape")
+    if len(nbits) < 1 or len(nbits) > 8:
+        raise CtHipError("regrain: nbits needs 1..8 entries")
+    a, b = img_in.double().contiguous(), img_col.double().contiguous()
+    h, w = a.shape[0], a.shape[1]
+    if out is None:
+        out = torch.empty_like(a)
+    ws = workspace(CT_WS_LAB_STATS, 0, 1, a.device, need=lib().ct_regrain_workspace_bytes(h, w))
+    nb = (ctypes.c_int * len(nbits))(*[int(v) for v in nbits])
+    check(lib().ct_regrain_f64(_ptr(a), _ptr(b), _ptr(out), h, w, ctypes.cast(nb, ctypes.c_void_p), len(nbits), _ptr(ws), ws.numel(),
+                               _stream()))
     return out
 
 

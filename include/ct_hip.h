@@ -134,6 +134,17 @@ int ct_affine3x3_f64_f64(const double *in, const double *coef, double *out, int6
 int ct_affine3x3_f32_f32(const float *in, const double *coef, float *out, int64_t n_pixels,
                          int batch, void *stream);
 
+/* ---- regrain: the second half of methods.iterative.automated_color_grading (methods/iterative.py:62-138) ----------------
+ * img_in (the original target), img_col (the IDT result), out: device [height][width][3] float64, one frame per call; out
+ * must not alias the inputs.  Multigrid as in the reference: both images are halved with skimage.transform.resize
+ * semantics (Gaussian anti-aliasing sigma (factor-1)/2 with 'mirror' boundary, then bilinear sampling with 'reflect'
+ * boundary; scikit-image 0.18.3) while (h+1)/2 > 20 and (w+1)/2 > 20 and nbits has entries left; on every level nbits[level]
+ * Jacobi sweeps of iterative.py:106-115.  nbits: HOST array, the reference's default is {4, 16, 32, 64, 64, 64}.
+ * ws: ct_regrain_workspace_bytes(height, width) (16-byte aligned).                                                     */
+size_t ct_regrain_workspace_bytes(int height, int width);
+int ct_regrain_f64(const double *img_in, const double *img_col, double *out, int height, int width, const int *nbits,
+                   int n_nbits, void *ws, size_t ws_bytes, void *stream);
+
 /* ---- per-frame metric (first step): PSNR as Runner.test_step logs it (methods/__init__.py:32,37) ----
  * a, b: [batch][n_elems] float32 (any layout, same for both); out[i] = {mse, 10 log10(1/mse)} (data range 1).
  * Deterministic float64 reduction.  ws: batch * 1024 doubles (ct_workspace_bytes(CT_WS_LAB_STATS, ., batch) suffices). */
