@@ -86,6 +86,8 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    from utils.sharding import pin_rank_to_cpus
+    pin_rank_to_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))      # one CPU slice per rank, before any GPU call
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -143,6 +145,7 @@ def main():
 
     # ---- per-kernel roofline: HIP events around each launch group on the launch stream ----------
     roof = None
+    roof_cnn = None
     extra = {}
     if rank == 0:
         # exact per-kernel durations: the library records HIP events on the launch stream right before / after
@@ -234,14 +237,29 @@ def main():
             flop = 512 * 512 * (6591040 + 390 * 512)
             extra["dcmcs3di_512_pairs_per_s_f32"] = dc
             extra["dcmcs3di_512_tflops"] = flop * dc / 1e12
-            extra["dcmcs3di_512_frac_fp32_mfma_peak"] = flop * dc / 157.3e12
             extra["dcmcs3di_512_frac_bf16_mfma_peak_x6"] = 6 * flop * dc / 2.5e15   # six bf16 MFMA flops per algorithmic flop
             # the size BASELINE.json's metric names: 1920x1080 (H*W*(6591040 + 390*W) FLOP/pair)
             l1080, r1080 = torch.rand(1, 3, H, W, device=device), torch.rand(1, 3, H, W, device=device)
-            dc2 = rate(lambda: net(l1080, r1080, inference=True), n=2)
+            dc2 = rate(lambda: net(l1080, r1080, inference=True), n=3)
             flop2 = H * W * (6591040 + 390 * W)
             extra["dcmcs3di_1080p_pairs_per_s_f32"] = dc2
-            extra["dcmcs3di_1080p_frac_fp32_mfma_peak"] = flop2 * dc2 / 157.3e12
+            # the second roofline object: the CNN half of BASELINE.json's metric.  bound = the bf16 matrix pipe (the one the
+            # kernels run on: 6 bf16 MFMAs per float32 product in the convolutions and the q.k scores); `frac` = MFMA-busy from
+            # the committed counter profile of the same forward (SQ_VALU_MFMA_BUSY_CYCLES over all kernels of the run, time
+            # weighted, profiles/r02_dcmcs3di_1080p_mfma_pmc.json); achieved = issued bf16-MFMA-equivalent work, live.
+            pm = os.path.join(ROOT, "profiles", "r02_dcmcs3di_1080p_mfma_pmc.json")
+            busy = json.load(open(pm)) if os.path.exists(pm) else {}
+            k33 = [v for k, v in busy.items() if "conv_split_kernel<3, 3" in k]
+            roof_cnn = {"bound": "mfma", "workload": "dcmcs3di forward, random init, 1 pair of 1920x1080, float32 I/O",
+                        "dtype": "bf16 MFMA pipe (float32 operands as 3 bf16 pieces, 6 MFMAs per product), f32 accumulate",
+                        "achieved": 6 * flop2 * dc2 / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                        "frac_flops": 6 * flop2 * dc2 / 2.5e15,
+                        "frac": busy.get("_all_kernels", {}).get("mfma_busy_frac_time_weighted"),
+                        "frac_definition": "MFMA-busy: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), time-weighted over every "
+                                           "kernel of the forward (rocprofv3 --pmc, profiles/r02_dcmcs3di_1080p_mfma_pmc.json)",
+                        "dominant_kernel": "conv_split_kernel<3,3>",
+                        "dominant_kernel_mfma_busy": k33[0].get("mfma_busy_frac") if k33 else None,
+                        "pairs_per_s": dc2, "algorithmic_f32_tflops": flop2 * dc2 / 1e12}
             del net, l1080, r1080
             # configs[3]: GMFlow matcher as DMSCT calls it (bidirectional + occlusion), random init, 540x960 -> 512x896
             from unimatch import GMFlow
@@ -251,7 +269,10 @@ def main():
             size = DMSCT.derive_matcher_inference_size(a960.shape)
             gr = rate(lambda: gm(a960, b960, inference_size=size, pred_bidir_flow=True, fwd_bwd_consistency_check=True), n=3)
             extra["gmflow_960x540_pairs_per_s_f32"] = gr
-            extra["gmflow_960x540_frac_fp32_mfma_peak"] = 3.58357106688e12 * gr / 157.3e12
+            extra["gmflow_960x540_tflops_f32_equivalent"] = 3.58357106688e12 * gr / 1e12
+            pm = os.path.join(ROOT, "profiles", "r02_gmflow_960x540_mfma_pmc.json")
+            if os.path.exists(pm):
+                extra["gmflow_960x540_mfma_busy_time_weighted"] = json.load(open(pm)).get("_all_kernels", {}).get("mfma_busy_frac_time_weighted")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -270,7 +291,7 @@ def main():
                        "pairs_per_step_per_gpu": B, "io_dtype": "float32", "height": H, "width": W,
                        "lab_arithmetic": ct_hip.lab_mode(), "metrics": names,
                        "sharding": "frame f -> rank f % world; one all_gather of the [frames, n_metrics] table"},
-            "roofline": roof, "cpu_baseline": cpu, "extra": extra,
+            "roofline": roof, "roofline_cnn": roof_cnn, "cpu_baseline": cpu, "extra": extra,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -47,6 +47,7 @@ SIGNATURES = {
     "ct_mk_f32_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_int, _c_p, _c_sz, _c_p]),
     "ct_mk_f64_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_int, _c_p, _c_sz, _c_p]),
     "ct_frame_psnr_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
+    "ct_distort_u8": (_c_int, [_c_p, _c_int, _c_int, _c_int, ctypes.c_double, _c_p, _c_p, _c_p, _c_sz, _c_p]),
     "ct_regrain_workspace_bytes": (_c_sz, [_c_int, _c_int]),
     "ct_regrain_f64": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_p, _c_int, _c_p, _c_sz, _c_p]),
     "ct_metric_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
@@ -279,6 +280,27 @@ def frame_psnr(a, b):
     ws = workspace(CT_WS_LAB_STATS, n, B, a.device)
     check(lib().ct_frame_psnr_f32(_ptr(a), _ptr(b), n, B, _ptr(out), _ptr(ws), ws.numel(), _stream()))
     return out
+
+
+DISTORTIONS = {"identity": 0, "brightness": 1, "contrast": 2, "saturation": 3, "hue": 4, "gamma": 5}
+
+
+def distort_u8(img, kind, param, want_u8=False):
+    """torchvision.transforms.functional.adjust_<kind>(img, param) on a uint8 [3,H,W] device tensor (utils/data.py:12-22).
+    Returns the distorted frame / 255 as float32 [3,H,W] (and the uint8 frame when want_u8)."""
+    if not img.is_cuda or img.dtype != torch.uint8 or img.dim() != 3 or img.shape[0] != 3 or not img.is_contiguous():
+        raise CtHipError("distort_u8 needs a contiguous uint8 [3,H,W] device tensor")
+    _check_device(img)
+    h, w = img.shape[1], img.shape[2]
+    out_f = torch.empty((3, h, w), dtype=torch.float32, device=img.device)
+    out_u = torch.empty_like(img) if want_u8 else None
+    ws = workspace(CT_WS_LAB_STATS, 0, 1, img.device, need=64)
+    rc = lib().ct_distort_u8(_ptr(img), h, w, DISTORTIONS[kind] if isinstance(kind, str) else int(kind), float(param),
+                             _ptr(out_u) if want_u8 else ctypes.c_void_p(0), _ptr(out_f), _ptr(ws), ws.numel(), _stream())
+    if rc == -1:
+        raise ValueError("distortion %r: parameter %r out of range" % (kind, param))      # torchvision raises ValueError too
+    check(rc)
+    return (out_f, out_u) if want_u8 else out_f
 
 
 def regrain(img_in, img_col, nbits=(4, 16, 32, 64, 64, 64), out=None):

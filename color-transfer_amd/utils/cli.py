@@ -54,6 +54,7 @@ def main(argv=None):
     import torch.distributed as dist
     from utils import sharding as sh
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    sh.pin_rank_to_cpus(int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("LOCAL_WORLD_SIZE", world)))   # before any GPU call
     device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
     torch.cuda.set_device(device)
     if world > 1:
@@ -73,9 +74,10 @@ def main(argv=None):
     frames = _instantiate(data_cfg).test_frames()
     mine = sh.frames_of_rank(len(frames), rank, world)
     from methods import METRICS, icid, psnr, ssim
+    from utils.data import prefetch
     rows = []
-    for f in mine:
-        batch = {k: v.unsqueeze(0).to(device) for k, v in frames[f].items()}
+    for f, sample in prefetch(frames, mine, device):       # pinned double-buffered uploads on a second stream
+        batch = {k: v.unsqueeze(0) for k, v in sample.items()}
         if hasattr(model, "test_step"):
             m = model.test_step(batch, f)
             rows.append(torch.stack([m[k].reshape(()) for k in METRICS]))

@@ -11,6 +11,23 @@ import torch
 import torch.distributed as dist
 
 
+def pin_rank_to_cpus(local_rank, local_world):
+    """One process per GPU: give rank r the r-th contiguous slice of the CPUs this process may run on (NUMA nodes are
+    contiguous CPU ranges and GPUs 0..3 / 4..7 hang off socket 0 / 1 on the 8-GPU MI355X nodes), so that the launch threads
+    of different ranks do not migrate across sockets or share cores.  Call BEFORE the first GPU call (the HIP runtime's
+    helper threads inherit the mask).  Returns the CPU list (or None when the platform has no sched_setaffinity)."""
+    import os
+    if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    cpus = sorted(os.sched_getaffinity(0))
+    per = len(cpus) // local_world
+    if per < 1:
+        return None
+    mine = cpus[local_rank * per:(local_rank + 1) * per]
+    os.sched_setaffinity(0, mine)
+    return mine
+
+
 def frames_of_rank(n_frames, rank, world):
     """Frame indices owned by `rank`: rank, rank + world, ..."""
     return list(range(rank, n_frames, world))

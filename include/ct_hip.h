@@ -145,6 +145,16 @@ size_t ct_regrain_workspace_bytes(int height, int width);
 int ct_regrain_f64(const double *img_in, const double *img_col, double *out, int height, int width, const int *nbits,
                    int n_nbits, void *ws, size_t ws_bytes, void *stream);
 
+/* ---- test-set distortions (utils/data.py:12-22,120-125): torchvision.transforms.functional.adjust_* on a uint8 frame ----
+ * in: uint8 [3][height][width] (what read_image returns).  kind: 0 identity, 1 brightness, 2 contrast, 3 saturation
+ * (param = factor >= 0), 4 hue (param = hue_factor in [-0.5, 0.5]), 5 gamma (param = gamma >= 0, gain 1).
+ * out_u8 (optional): the distorted uint8 frame; out_f32 (optional): that frame / 255 as float32 [3][H][W] -- the
+ * `target / 255` the dataset hands over.  torchvision's tensor-backend arithmetic restated (float32, truncating casts; the
+ * Python-float factor and 1 - factor are each rounded to float32, hence the double parameter).
+ * ws: >= 8 bytes, 8-byte aligned.                                                                                      */
+int ct_distort_u8(const uint8_t *in, int height, int width, int kind, double param, uint8_t *out_u8, float *out_f32,
+                  void *ws, size_t ws_bytes, void *stream);
+
 /* ---- per-frame metric (first step): PSNR as Runner.test_step logs it (methods/__init__.py:32,37) ----
  * a, b: [batch][n_elems] float32 (any layout, same for both); out[i] = {mse, 10 log10(1/mse)} (data range 1).
  * Deterministic float64 reduction.  ws: batch * 1024 doubles (ct_workspace_bytes(CT_WS_LAB_STATS, ., batch) suffices). */
