@@ -39,13 +39,18 @@ static_assert(kLdsC >= kCFirst * 16, "table C is addressed with a negative bias"
 template <int THREADS, int N>
 __device__ __forceinline__ void copy16(const uint4 *__restrict__ src, uint4 *dst) {
     constexpr int STEPS = (N + THREADS - 1) / THREADS;
-    uint4 v[STEPS];
-#pragma unroll
-    for (int k = 0; k < STEPS; ++k)
-        if (k * THREADS + (int)threadIdx.x < N) v[k] = src[k * THREADS + threadIdx.x];
-#pragma unroll
-    for (int k = 0; k < STEPS; ++k)
-        if (k * THREADS + (int)threadIdx.x < N) dst[k * THREADS + threadIdx.x] = v[k];
+    static_assert(STEPS <= 4, "tables of at most 4 x THREADS x 16 bytes");
+    const int t = threadIdx.x;
+    // named registers (an indexed local array ends up in scratch memory here)
+    uint4 v0 = {}, v1 = {}, v2 = {}, v3 = {};
+    if (STEPS > 0 && t < N) v0 = src[t];
+    if (STEPS > 1 && THREADS + t < N) v1 = src[THREADS + t];
+    if (STEPS > 2 && 2 * THREADS + t < N) v2 = src[2 * THREADS + t];
+    if (STEPS > 3 && 3 * THREADS + t < N) v3 = src[3 * THREADS + t];
+    if (STEPS > 0 && t < N) dst[t] = v0;
+    if (STEPS > 1 && THREADS + t < N) dst[THREADS + t] = v1;
+    if (STEPS > 2 && 2 * THREADS + t < N) dst[2 * THREADS + t] = v2;
+    if (STEPS > 3 && 3 * THREADS + t < N) dst[3 * THREADS + t] = v3;
 }
 template <int THREADS, bool WITH_C>
 __device__ __forceinline__ void load_tables(unsigned char *lds) {

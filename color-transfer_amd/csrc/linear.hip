@@ -460,7 +460,10 @@ __global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_APPLY) void reinhard_apply_lu
                                                                                          float *__restrict__ out, int64_t n_pixels,
                                                                                          const double *__restrict__ partials,
                                                                                          const double *__restrict__ pivots, int n_partials,
-                                                                                         int batch, double *__restrict__ stats_out) {
+                                                                                         int batch, double *__restrict__ stats_out,
+                                                                                         const float *__restrict__ gt, double *__restrict__ sq_partials) {
+    // gt != NULL: the per-frame squared error of the result against a ground-truth frame (the PSNR of Runner.test_step,
+    // methods/__init__.py:32) is accumulated on the way out -- the corrected frame is not read back from HBM for it
     __shared__ __attribute__((aligned(16))) unsigned char tab[OUT_LAB ? lut::kLdsBytesFwd : lut::kLdsBytesAll];
     __shared__ double fin[12 * 8 + 2 * CT_LAB_STATS_STRIDE];
     const int img = blockIdx.y;
@@ -517,6 +520,7 @@ __global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_APPLY) void reinhard_apply_lu
     // constant target gives inf / nan like the reference -- goes through the exact code
     const double cmax = fmax(fmax(fmax(fabs(c.sL), fabs(c.sa)), fmax(fabs(c.sb), fabs(c.cy))), fmax(fabs(c.ca), fabs(c.cb)));
     const bool coef_bad = !(cmax < 1e6);
+    double sq = 0.0;
     __syncthreads();
     for (; t < n_full; t += stride) {
 #if CT_LUT_PREFETCH
@@ -553,6 +557,14 @@ __global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_APPLY) void reinhard_apply_lu
             }
         }
         store_tile(o + t * (kTilePixels * 3), lane, w);
+        if (gt != nullptr) {
+            float gv[12];
+            load_tile(gt + ((size_t)img * n_pixels + (size_t)t * kTilePixels) * 3, lane, gv);
+            float e = 0.f;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { const float d = w[i] - gv[i]; e = fmaf(d, d, e); }
+            sq += (double)e;
+        }
 #if CT_LUT_PREFETCH
 #pragma unroll
         for (int i = 0; i < 12; ++i) cur[i] = nxt[i];
@@ -566,7 +578,18 @@ __global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_APPLY) void reinhard_apply_lu
             float a, b, d;
             reinhard_pixel<float, OUT_LAB>(c, (double)p[px * 3], (double)p[px * 3 + 1], (double)p[px * 3 + 2], a, b, d);
             o[px * 3] = a; o[px * 3 + 1] = b; o[px * 3 + 2] = d;
+            if (gt != nullptr) {
+                const float *gp = gt + ((size_t)img * n_pixels + px) * 3;
+                const double d0 = (double)a - gp[0], d1 = (double)b - gp[1], d2 = (double)d - gp[2];
+                sq += (d0 * d0 + d1 * d1) + d2 * d2;
+            }
         }
+    }
+    if (gt != nullptr) {                                             // uniform per launch
+        double v[1] = {sq};
+        __syncthreads();                                             // fin[] is free again
+        block_sum_n<1, kLutWaves>(v, fin);
+        if (threadIdx.x == 0) sq_partials[(size_t)img * kMaxBlocksPerImage + blockIdx.x] = v[0];
     }
 }
 
@@ -860,7 +883,8 @@ static int launch_moments(const T *base0, const T *base1, int n_first, int n_ima
 template <typename T, bool OUT_LAB>
 static int launch_reinhard_apply(const T *target, const double *st, const double *sr, T *out, int64_t n_pixels,
                                  int batch, hipStream_t s, const WsLayout *deferred = nullptr, int n_partials = 0,
-                                 double *stats_out = nullptr) {
+                                 double *stats_out = nullptr, const float *gt = nullptr, double *sq_partials = nullptr,
+                                 int *sq_blocks = nullptr) {
     if (batch == 0 || n_pixels == 0) return CT_OK;
     constexpr bool kLut = sizeof(T) == 4;
     const bool use_lut = kLut && g_lab_mode == 0;
@@ -874,7 +898,8 @@ static int launch_reinhard_apply(const T *target, const double *st, const double
         if (use_lut)
             hipLaunchKernelGGL((reinhard_apply_lut_kernel<OUT_LAB>), dim3(G, batch), dim3(kLutBlock), 0, s, target, st, sr, out,
                                n_pixels, (const double *)(deferred ? deferred->partials : nullptr),
-                               (const double *)(deferred ? deferred->pivots : nullptr), n_partials, batch, stats_out);
+                               (const double *)(deferred ? deferred->pivots : nullptr), n_partials, batch, stats_out, gt, sq_partials);
+        if (use_lut && sq_blocks) *sq_blocks = G;
     }
     if (!use_lut)
         hipLaunchKernelGGL((reinhard_apply_kernel<T, OUT_LAB>), dim3(G, batch), dim3(kBlock), 0, s, target, st, sr, out,
@@ -977,6 +1002,42 @@ __global__ __launch_bounds__(kBlock) void psnr_finish_kernel(const double *__res
     }
 }
 
+// a1 fused with the per-frame PSNR of Runner.test_step (methods/__init__.py:30-32,37): color_transfer_between_images for
+// `batch` pairs + PSNR(result, gt) per frame.  Table path: the squared error is accumulated by the apply sweep while it
+// writes the result (one extra plane read, the result is never read back); exact path: the two steps one after the other.
+// Workspace: the Reinhard layout followed by batch x kMaxBlocksPerImage doubles.
+static size_t ws_bytes_reinhard_psnr(int batch) { return ws_bytes_for(2 * batch) + (size_t)batch * kMaxBlocksPerImage * sizeof(double); }
+
+static int reinhard_psnr_impl(const float *target, const float *reference, const float *gt, float *out, double *psnr_out,
+                              int64_t n_pixels, int batch, double *stats_out, void *ws, size_t ws_bytes, void *stream) {
+    int rc = check_image_args(target, n_pixels, batch);
+    if (rc) return rc;
+    if ((rc = check_image_args(reference, n_pixels, batch))) return rc;
+    if ((rc = check_image_args(gt, n_pixels, batch))) return rc;
+    if ((rc = check_image_args(out, n_pixels, batch))) return rc;
+    if (batch > 0 && psnr_out == nullptr) return CT_E_BADARG;
+    if (ws == nullptr || (reinterpret_cast<uintptr_t>(ws) & 15) || ws_bytes < ws_bytes_reinhard_psnr(batch)) return CT_E_WORKSPACE;
+    if (batch == 0 || n_pixels == 0) return CT_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const WsLayout l = ws_carve(ws, 2 * batch);
+    double *sq = reinterpret_cast<double *>(reinterpret_cast<char *>(ws) + ws_bytes_for(2 * batch));
+    double *stats = stats_out ? stats_out : l.stats;
+    int deferred = 0, sq_blocks = 0;
+    rc = launch_moments<float, true>(target, reference, batch, 2 * batch, n_pixels, l, stats, s, &deferred);
+    if (rc) return rc;
+    rc = launch_reinhard_apply<float, false>(target, stats, stats + (size_t)batch * CT_LAB_STATS_STRIDE, out, n_pixels, batch, s,
+                                             deferred > 0 ? &l : nullptr, deferred, stats, deferred > 0 ? gt : nullptr, sq, &sq_blocks);
+    if (rc) return rc;
+    if (sq_blocks == 0) {                       // exact path: a sweep of its own over (out, gt)
+        sq_blocks = blocks_per_image((n_pixels * 3) >> 2, batch);
+        hipLaunchKernelGGL(sqerr_partial_kernel, dim3(sq_blocks, batch), dim3(kBlock), 0, s, (const float *)out, gt, n_pixels * 3, sq);
+        CT_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(psnr_finish_kernel, dim3(batch), dim3(kBlock), 0, s, (const double *)sq, sq_blocks, n_pixels * 3, psnr_out);
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+}
+
 // a3 fused: moments of all 2*batch images in one sweep, finishing kernel, 3x3 algebra, affine apply -- no host sync
 template <typename T, typename TO>
 static int mk_impl(const T *target, const T *reference, TO *out, int64_t n_pixels, int batch, int decomposition, void *ws,
@@ -1040,6 +1101,7 @@ size_t ct_workspace_bytes(int kind, int64_t n_pixels, int n_images) {
         case CT_WS_LAB_STATS:
         case CT_WS_RGB_MEANCOV: return ct::ws_bytes_for(n_images);
         case CT_WS_REINHARD: return ct::ws_bytes_for(2 * n_images);
+        case CT_WS_REINHARD_PSNR: return ct::ws_bytes_reinhard_psnr(n_images);
         default: return 0;
     }
 }
@@ -1087,6 +1149,10 @@ int ct_reinhard_f32(const float *target, const float *reference, float *out, int
 int ct_reinhard_f64(const double *target, const double *reference, double *out, int64_t n_pixels, int batch,
                     double *stats_out, void *ws, size_t ws_bytes, void *stream) {
     return ct::reinhard_impl<double>(target, reference, out, n_pixels, batch, stats_out, ws, ws_bytes, stream);
+}
+int ct_reinhard_psnr_f32(const float *target, const float *reference, const float *gt, float *out, double *psnr_out, int64_t n_pixels,
+                         int batch, double *stats_out, void *ws, size_t ws_bytes, void *stream) {
+    return ct::reinhard_psnr_impl(target, reference, gt, out, psnr_out, n_pixels, batch, stats_out, ws, ws_bytes, stream);
 }
 
 int ct_rgb_meancov_f32(const float *rgb, int64_t n_pixels, int n_images, double *stats, void *ws, size_t ws_bytes,

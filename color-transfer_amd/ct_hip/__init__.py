@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("CT_HIP_LIB") or os.path.join(_HERE, "libct_hip.so")  
 
 CT_LAB_STATS_STRIDE = 8
 CT_RGB_STATS_STRIDE = 16
-CT_WS_LAB_STATS, CT_WS_RGB_MEANCOV, CT_WS_REINHARD, CT_WS_IDT = 0, 1, 2, 3
+CT_WS_LAB_STATS, CT_WS_RGB_MEANCOV, CT_WS_REINHARD, CT_WS_IDT, CT_WS_REINHARD_PSNR = 0, 1, 2, 3, 4
 
 _c_i64 = ctypes.c_int64
 _c_int = ctypes.c_int
@@ -41,6 +41,7 @@ SIGNATURES = {
     "ct_reinhard_lab_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_int, _c_p]),
     "ct_reinhard_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
     "ct_reinhard_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
+    "ct_reinhard_psnr_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
     "ct_rgb_meancov_f32": (_c_int, [_c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
     "ct_rgb_meancov_f64": (_c_int, [_c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
     "ct_mk_f32_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_int, _c_p, _c_sz, _c_p]),
@@ -248,6 +249,26 @@ def reinhard(target, reference, out=None, stats_out=None):
     sp = _ptr(stats_out) if stats_out is not None else ctypes.c_void_p(0)
     check(fn(_ptr(x), _ptr(r), _ptr(out), n, B, sp, _ptr(ws), ws.numel(), _stream()))
     return out.view(target.shape)
+
+
+def reinhard_psnr(target, reference, gt, out=None, psnr_out=None):
+    """color_transfer_between_images for B float32 pairs + the per-frame PSNR of the result against `gt` (same layout as the
+    images), as Runner.test_step computes it (methods/__init__.py:30-32).  Returns (out, psnr float64 [B, 2] = mse, PSNR)."""
+    x, _ = _as_batch(target)
+    r, _ = _as_batch(reference)
+    g, _ = _as_batch(gt)
+    _require_cuda(x, r, g)
+    if not (x.shape == r.shape == g.shape) or not (x.dtype == r.dtype == g.dtype == torch.float32):
+        raise CtHipError("reinhard_psnr needs three float32 tensors of one shape")
+    B, n = x.shape[0], x.shape[1] * x.shape[2]
+    if out is None:
+        out = torch.empty_like(x)
+    if psnr_out is None:
+        psnr_out = torch.empty((B, 2), dtype=torch.float64, device=x.device)
+    ws = workspace(CT_WS_REINHARD_PSNR, n, B, x.device)
+    check(lib().ct_reinhard_psnr_f32(_ptr(x), _ptr(r), _ptr(g), _ptr(out), _ptr(psnr_out), n, B, ctypes.c_void_p(0), _ptr(ws), ws.numel(),
+                                     _stream()))
+    return out.view(target.shape), psnr_out
 
 
 def mk(target, reference, decomposition="MK", out_dtype=torch.float64, out=None):

@@ -43,7 +43,8 @@ enum ct_workspace_kind {
     CT_WS_LAB_STATS = 0, /* ct_lab_stats_*: n_images = number of images in the call    */
     CT_WS_RGB_MEANCOV = 1,
     CT_WS_REINHARD = 2,  /* ct_reinhard_*:  n_images = batch (pairs)                    */
-    CT_WS_IDT = 3        /* ct_idt_*:       n_images = batch (pairs)                    */
+    CT_WS_IDT = 3,       /* ct_idt_*:       n_images = batch (pairs)                    */
+    CT_WS_REINHARD_PSNR = 4 /* ct_reinhard_psnr_f32: n_images = batch (pairs)           */
 };
 
 int ct_abi_version(void);
@@ -97,6 +98,12 @@ int ct_reinhard_f32(const float *target, const float *reference, float *out,
 int ct_reinhard_f64(const double *target, const double *reference, double *out,
                     int64_t n_pixels, int batch, double *stats_out, void *ws, size_t ws_bytes,
                     void *stream);
+/* The same + the per-frame PSNR of Runner.test_step (methods/__init__.py:30-32,37) against ground-truth frames gt
+ * ([batch][n_pixels][3] like the images): psnr_out[i] = {mse, 10 log10(1 / mse)} of the (clipped) result of pair i.
+ * With the table arithmetic the squared error is accumulated by the apply sweep while it writes the result -- the result is
+ * not read back from HBM.  ws: ct_workspace_bytes(CT_WS_REINHARD_PSNR, n_pixels, batch).                               */
+int ct_reinhard_psnr_f32(const float *target, const float *reference, const float *gt, float *out, double *psnr_out,
+                         int64_t n_pixels, int batch, double *stats_out, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- A3: np.mean(axis=0) + np.cov(x.T)   (methods/linear.py:64-67,103-106) ----
  * stats[i*16 ..] = {mean[3] ; cov[9] row-major, ddof 1 ; n ; 0 0 0}.                     */

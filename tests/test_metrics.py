@@ -113,3 +113,22 @@ def test_runner_test_step_reports_all_metrics(hip):
     assert abs(float(m["Test iCID"][1]) - float(om.icid(res[1:2], y[1:2]))) < 5e-6
     with pytest.raises(hip.CtHipError):
         hip.frame_ssim(torch.rand(1, 3, 8, 8).cuda(), torch.rand(1, 3, 8, 8).cuda())      # smaller than the 11x11 window
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["table", "exact"])
+def test_fused_reinhard_psnr(hip, mode):
+    """ct_reinhard_psnr_f32 == ct_reinhard_f32 followed by ct_frame_psnr_f32 (same result image bit for bit, same PSNR)"""
+    gen = torch.Generator().manual_seed(4)
+    for shape in ((3, 67, 91, 3), (2, 256, 300, 3), (1, 5, 7, 3)):
+        t, r, g = (torch.rand(shape, generator=gen).cuda() for _ in range(3))
+        hip.set_lab_mode(mode)
+        try:
+            out, ps = hip.reinhard_psnr(t, r, g)
+            want = hip.reinhard(t, r)
+            want_ps = hip.frame_psnr(want, g)
+        finally:
+            hip.set_lab_mode("table")
+        assert torch.equal(out, want)
+        assert torch.allclose(ps, want_ps, rtol=1e-6, atol=0), (ps, want_ps)          # float32 per-tile partial sums vs float64
+        assert torch.allclose(ps[:, 1].cpu(), om.psnr(out.cpu(), g.cpu()), atol=1e-5)
