@@ -503,6 +503,239 @@ __device__ __forceinline__ void mfma_split6(f32x16g &s, const uint4 (&a)[3], con
     s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, s, 0, 0, 0);
     s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, s, 0, 0, 0);
 }
+// =================================================================================================
+// nn.Linear on channels-last tokens on the bf16 matrix pipe ("split", float32-grade accuracy: conv_split.hip's arithmetic).
+// A workgroup owns MT (128 or 64) tokens x 128 features, its 4 waves MT/2 x 64 quarters; K is walked in chunks of 32
+// channels = two v_mfma_f32_32x32x16_bf16 K steps, six MFMAs per product.
+//   W: pre-split on the host in exactly the LDS image of a chunk ([piece][8-channel group][feature row] x 16 bytes,
+//      ct_hip.pack_linear_weight_split): staging is a linear 24 KiB copy through registers, fetched one chunk ahead.
+//   X: split in registers while it is staged (a thread owns 8 consecutive channels of a token = one MFMA fragment per
+//      piece), into a DOUBLE-buffered LDS image: the split of chunk c+1 (VALU) runs between the MFMAs of chunk c, the raw
+//      loads are issued two chunks ahead.  Group stride MT+4 rows: the 16 lanes of a ds_write_b128 pass hit 16 distinct
+//      bank groups; fragment reads are 32 consecutive rows of one group = conflict free.
+// Two barriers per chunk (X/W of the chunk visible; W consumed), only the short W copy sits between them.  LDS 73.5 KiB
+// (MT = 128): two workgroups per CU, so one's prologue / epilogue (bias, GELU, transpose, stores) runs under the other's MFMAs.
+// Several feature tiles (N > 128): 1-D grid ordered so that the tiles of one token block run at the same time on the same
+// XCD (workgroup b is placed on XCD b % 8) -- the block's tokens come from HBM once and from that XCD's L2 afterwards.
+// K % 32 == 0.
+// =================================================================================================
+constexpr int kLsW = 3 * 4 * 128;                 // uint4 entries of the W image (= one packed chunk)
+#ifdef CT_LS_PROFILE
+// diagnostic build (tools/build_variant.sh, never shipped): per-phase s_memtime totals of wave 0 of every workgroup
+__device__ unsigned long long g_ls_prof[8];
+#define LS_STAMP(var) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#define LS_PHASE(i) do { unsigned long long t__; LS_STAMP(t__); pt[i] += t__ - pt0; pt0 = t__; } while (0)
+#else
+#define LS_PHASE(i) do { } while (0)
+#endif
+
+// GELU(v) = v Phi(v) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. float32 rounding level of
+// the result; branch free: one v_rcp_f32, one v_exp_f32, seven FMAs) instead of the library erff (two branches, both of
+// which a wave executes) -- the epilogue of the 1024-wide FFN layer evaluates it 16384 times per workgroup.
+__device__ __forceinline__ float gelu_as(float v) {
+    const float z = fabsf(v) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
+    const float erfc_half = 0.5f * p * t * e;                       // erfc(z) / 2
+    return v > 0.f ? v - v * erfc_half : v * erfc_half;           // v Phi(v), Phi(-z sqrt2) = erfc(z) / 2
+}
+
+template <int MT>
+__global__ __launch_bounds__(256, 2) void linear_split_kernel(const float *__restrict__ x, const float *__restrict__ x2, int K1,
+                                                              const uint4 *__restrict__ wp, const float *__restrict__ bias,
+                                                              float *__restrict__ out, long long T, int K, int N, int act,
+                                                              int n_nt) {
+    constexpr int MI = MT / 64;                   // 32-token MFMA tiles per wave (and X staging units per thread)
+    constexpr int XR = MT + 4;                    // rows per (piece, group) of an X image
+    constexpr int XIMG = 3 * 4 * XR;              // uint4 entries of one X image
+    __shared__ uint4 lds[2 * XIMG + kLsW];
+    uint4 *Ws = lds + 2 * XIMG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, hl = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+    // tile of this workgroup: logical ids run XCD-major, feature tile fastest
+    unsigned int lid = blockIdx.x;
+    if (n_nt > 1 && (gridDim.x & 7) == 0) lid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int nt = (int)(lid % (unsigned)n_nt);
+    const long long t0 = (long long)(lid / (unsigned)n_nt) * MT;
+    const int n0 = nt * 128;
+    const int n_chunks = K >> 5;
+    const uint4 *wsrc = wp + (size_t)nt * n_chunks * kLsW + tid;
+    // X staging: unit u = tid + 256 i -> (token row u >> 2, 8-channel group u & 3): four lanes read one token's 128 bytes
+    const int srow = tid >> 2, sg = tid & 3;
+    long long xr[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const long long tr = t0 + srow + 64 * i;
+        xr[i] = tr < T ? tr : T - 1;
+    }
+    const int K2 = K - K1;
+    float4 pa[MI][2], pb[MI][2];                  // raw X of chunk c+1 (being split) / chunk c+2 (in flight)
+    uint4 pw[6];
+    auto fetch_x = [&](int c, float4 (&px)[MI][2]) {
+        const int kc = c << 5;
+        const bool second = kc >= K1;          // uniform: a 32-channel chunk never straddles the two sources
+        const float *xs = second ? x2 + (kc - K1) + 8 * sg : x + kc + 8 * sg;
+        const int ld = second ? K2 : K1;
+#ifdef CT_LS_NOXLOAD
+        if (c > 1) return;
+#endif
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const float4 *p = reinterpret_cast<const float4 *>(xs + xr[i] * ld);
+            px[i][0] = p[0];
+            px[i][1] = p[1];
+        }
+    };
+    auto fetch_w = [&](int c) {
+#ifdef CT_LS_NOWLOAD
+        if (c > 1) return;
+#endif
+#pragma unroll
+        for (int j = 0; j < 6; ++j) pw[j] = wsrc[(size_t)c * kLsW + 256 * j];
+    };
+    auto split_unit = [&](const float4 (&px)[MI][2], int i, uint4 *img) {
+        const float v[8] = {px[i][0].x, px[i][0].y, px[i][0].z, px[i][0].w, px[i][1].x, px[i][1].y, px[i][1].z, px[i][1].w};
+        uint4 h, m, l;
+        split3x8g(v, h, m, l);
+        uint4 *d = img + sg * XR + srow + 64 * i;
+        d[0] = h;
+        d[4 * XR] = m;
+        d[8 * XR] = l;
+    };
+    auto store_w = [&]() {
+#ifdef CT_LS_NOWSTORE
+        if (pw[0].x != 0x12345u) return;
+#endif
+#pragma unroll
+        for (int j = 0; j < 6; ++j) Ws[tid + 256 * j] = pw[j];
+    };
+
+    f32x16g acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#ifdef CT_LS_PROFILE
+    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt0;
+    LS_STAMP(pt0);
+#endif
+    fetch_x(0, pb);
+    fetch_w(0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) split_unit(pb, i, lds);
+    store_w();
+    if (n_chunks > 1) {
+        fetch_x(1, pa);
+        fetch_w(1);
+    }
+    LS_PHASE(0);                               // prologue
+    const int xoff = hl * XR + wm * (MT / 2) + nl;
+    const uint4 *wb = Ws + hl * 128 + wn * 64 + nl;
+    // one chunk: `cur` holds the raw X of chunk c+1 (loaded a chunk ago), `nxt` receives chunk c+2
+    auto chunk = [&](int c, float4 (&cur)[MI][2], float4 (&nxt)[MI][2]) {
+#ifndef CT_LS_NOBAR
+        __syncthreads();                       // X image c & 1 and the W image hold chunk c
+#endif
+        LS_PHASE(1);
+        if (c + 2 < n_chunks) fetch_x(c + 2, nxt);
+        const uint4 *xa = lds + (c & 1) * XIMG + xoff;
+        uint4 *xn = lds + ((c + 1) & 1) * XIMG;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {          // K step: channels 16 s + 8 hl + 0..7 of the chunk
+            uint4 a[MI][3], b[2][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[i][p] = xa[(4 * p + 2 * s) * XR + 32 * i];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j][p] = wb[(4 * p + 2 * s) * 128 + 32 * j];
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mfma_split6(acc[i][j], a[i], b[j]);
+            // the split of chunk c+1 (one staging unit per K step) goes to the other image, its VALU work between the MFMAs
+            // above (after the last chunk it re-splits stale registers into the dead image: no branch in the schedule region)
+            if (s < MI) {
+                split_unit(cur, s, xn);
+#pragma unroll
+                for (int q = 0; q < 12 * MI; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, MI == 2 ? 3 : 6, 0);
+                }
+            }
+        }
+        LS_PHASE(2);
+#ifndef CT_LS_NOBAR
+        __syncthreads();                       // every wave is done with the W image
+#endif
+        LS_PHASE(3);
+        if (c + 1 < n_chunks) {
+            store_w();
+            if (c + 2 < n_chunks) fetch_w(c + 2);
+        }
+        LS_PHASE(4);
+    };
+    for (int c = 0; c < n_chunks; c += 2) {    // unrolled by two: the raw-X register sets swap roles without copies
+        chunk(c, pa, pb);
+        if (c + 1 < n_chunks) chunk(c + 1, pb, pa);
+    }
+
+    // epilogue: per-wave LDS transpose (the operand images are dead after the last barrier), 16-byte stores
+    float *stg = reinterpret_cast<float *>(lds) + wave * (32 * 32);
+    const bool wide = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int f0 = n0 + wn * 64 + j * 32;
+            const long long tt0 = t0 + wm * (MT / 2) + i * 32;
+            const int nf = f0 + nl;
+            const float bb = (bias && nf < N) ? bias[nf] : 0.f;
+            if (act == 6) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = gelu_as(acc[i][j][r] + bb);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += bb;
+            }
+            if (wide) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * hl) * 32 + nl] = acc[i][j][r];
+                __builtin_amdgcn_wave_barrier();
+                const int fc = f0 + 4 * (lane & 7);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = (lane >> 3) + 8 * g;
+                    const float4 v = *reinterpret_cast<const float4 *>(stg + row * 32 + 4 * (lane & 7));
+                    const long long t = tt0 + row;
+                    if (t < T && fc < N) *reinterpret_cast<float4 *>(out + t * N + fc) = v;   // N % 4 == 0: all four or none
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else if (nf < N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long t = tt0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+                    if (t < T) out[t * N + nf] = acc[i][j][r];
+                }
+            }
+        }
+#ifdef CT_LS_PROFILE
+    LS_PHASE(5);                               // epilogue
+    if (tid == 0) {
+        for (int i = 0; i < 7; ++i) atomicAdd(&g_ls_prof[i], pt[i]);
+        atomicAdd(&g_ls_prof[7], 1ull);
+    }
+#endif
+}
+
 constexpr int kSsRow(int C) { return 2 * C + 16; }   // bytes per LDS row of a split tile: 16-byte fragment reads are conflict free
 
 template <int C, int CV, bool MAP, bool SS>
@@ -1264,6 +1497,36 @@ int ct_linear_tokens_f32(const float *x, const float *x2, int k1, const float *w
     if (tokens == 0) return CT_OK;
     dim3 grid((unsigned)((tokens + 127) / 128), (n + 127) / 128);
     hipLaunchKernelGGL(ct::linear_tokens_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, x2, k1, w, bias, out, tokens, k, n, act);
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+}
+
+#ifdef CT_LS_PROFILE
+int ct_debug_ls_prof(unsigned long long *host8, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return CT_E_BADARG;
+    if (host8 && hipMemcpyFromSymbol(host8, HIP_SYMBOL(ct::g_ls_prof), 64) != hipSuccess) return CT_E_BADARG;
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(ct::g_ls_prof), z, 64) != hipSuccess) return CT_E_BADARG; }
+    return CT_OK;
+}
+#endif
+// wp: ct_hip.pack_linear_weight_split(weight): bf16 bit patterns [ceil(n/128)][k/32][piece hi/mid/lo][8-channel group 0..3]
+// [feature row 0..127][8 channels], zero rows beyond n.  k % 32 == 0 (k1 % 32 == 0 with x2).
+int ct_linear_tokens_split_f32(const float *x, const float *x2, int k1, const void *wp, const float *bias, float *out, long long tokens,
+                               int k, int n, int act, void *stream) {
+    if (!x || !wp || !out || tokens < 0 || k < 32 || (k % 32) || n < 1) return CT_E_BADARG;
+    if (x2 ? (k1 < 32 || k1 >= k || (k1 % 32)) : (k1 != k)) return CT_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wp) | reinterpret_cast<uintptr_t>(x2)) & 15) return CT_E_ALIGN;
+    if (tokens == 0) return CT_OK;
+    const int n_nt = (n + 127) / 128;
+    // 64-token tiles while 128-token tiles would leave CUs without a workgroup (2 per CU are resident)
+    const long long tiles128 = (tokens + 127) / 128 * n_nt;
+    if (tiles128 >= 2 * 256) {
+        hipLaunchKernelGGL(ct::linear_split_kernel<128>, dim3((unsigned)tiles128), dim3(256), 0, (hipStream_t)stream, x, x2, k1,
+                           (const uint4 *)wp, bias, out, tokens, k, n, act, n_nt);
+    } else {
+        hipLaunchKernelGGL(ct::linear_split_kernel<64>, dim3((unsigned)((tokens + 63) / 64 * n_nt)), dim3(256), 0, (hipStream_t)stream, x,
+                           x2, k1, (const uint4 *)wp, bias, out, tokens, k, n, act, n_nt);
+    }
     CT_CHECK_LAUNCH();
     return CT_OK;
 }

@@ -597,6 +597,7 @@ SIGNATURES.update({
     "ct_instance_norm_f32": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_f, _c_int, _c_p, ctypes.c_size_t, _c_p]),
     "ct_eltwise_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_f, _c_p]),
     "ct_linear_tokens_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p, ctypes.c_longlong, _c_int, _c_int, _c_int, _c_p]),
+    "ct_linear_tokens_split_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p, ctypes.c_longlong, _c_int, _c_int, _c_int, _c_p]),
     "ct_layernorm128_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_p]),
     "ct_attention_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int, _c_int, _c_int]),
     "ct_attention_tokens_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_int, _c_p,
@@ -692,9 +693,36 @@ def eltwise(op, a, b=None, c=None, plane=1, chans=1, split=0, s0=1.0):
     return y
 
 
-def linear_tokens(x, weight, bias=None, act=ACT_NONE, x2=None):
+def pack_linear_weight_split(weight):
+    """nn.Linear weight [N, K] (K % 32 == 0) -> ct_linear_tokens_split_f32's operand: bf16 bit patterns (int16)
+    [ceil(N/128)][K/32][piece hi/mid/lo][8-channel group 0..3][feature row 0..127][8 channels], zero rows beyond N."""
+    n, k = weight.shape
+    nt, nc = (n + 127) // 128, k // 32
+    w = torch.zeros((nt * 128, k), dtype=torch.float32, device=weight.device)
+    w[:n] = weight.detach().float()
+    hi = w.to(torch.bfloat16)
+    r1 = w - hi.float()
+    r1 = torch.where(torch.isfinite(r1), r1, torch.zeros_like(r1))
+    mid = r1.to(torch.bfloat16)
+    lo = (r1 - mid.float()).to(torch.bfloat16)
+    pieces = torch.stack([hi, mid, lo], dim=0).view(torch.int16)           # [3][ntile*128][K]
+    pieces = pieces.reshape(3, nt, 128, nc, 4, 8)                          # piece, tile, row, chunk, group, j
+    return pieces.permute(1, 3, 0, 4, 2, 5).contiguous()                   # tile, chunk, piece, group, row, j
+
+
+def _packed_linear(weight):
+    ver = (weight._version, weight.data_ptr(), str(weight.device))
+    hit = getattr(weight, "_ct_lin_split", None)
+    if hit is None or hit[0] != ver:
+        hit = (ver, pack_linear_weight_split(weight))
+        weight._ct_lin_split = hit
+    return hit[1]
+
+
+def linear_tokens(x, weight, bias=None, act=ACT_NONE, x2=None, mode=None):
     """x [..., K1] channels-last tokens (optionally concatenated with x2 [..., K2] on the fly), weight [N, K1+K2]
-    (PyTorch layout) -> [..., N]"""
+    (PyTorch layout) -> [..., N].  mode (default: conv_mode()): "split" = bf16 matrix pipe, float32-grade (K % 32 == 0; the
+    pre-split weight is cached on the weight tensor); "exact" = v_mfma_f32_32x32x2_f32."""
     _f32c(x, weight, bias, x2)
     k1, n = x.shape[-1], weight.shape[0]
     k = k1 + (x2.shape[-1] if x2 is not None else 0)
@@ -702,7 +730,11 @@ def linear_tokens(x, weight, bias=None, act=ACT_NONE, x2=None):
         raise CtHipError("linear_tokens: shape mismatch")
     t = x.numel() // k1
     out = torch.empty(x.shape[:-1] + (n,), dtype=torch.float32, device=x.device)
-    check(lib().ct_linear_tokens_f32(_ptr(x), _opt(x2), k1, _ptr(weight), _opt(bias), _ptr(out), t, k, n, int(act), _stream()))
+    if (mode or _conv_mode) == "split" and k % 32 == 0:
+        check(lib().ct_linear_tokens_split_f32(_ptr(x), _opt(x2), k1, _ptr(_packed_linear(weight)), _opt(bias), _ptr(out), t, k, n,
+                                               int(act), _stream()))
+    else:
+        check(lib().ct_linear_tokens_f32(_ptr(x), _opt(x2), k1, _ptr(weight), _opt(bias), _ptr(out), t, k, n, int(act), _stream()))
     return out
 
 

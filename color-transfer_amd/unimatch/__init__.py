@@ -147,7 +147,8 @@ def _conv(m, x, act=ACT_NONE, stride=None, padding=None, weight=None, x2=None, o
 
 
 def _lin(m, x, act=ACT_NONE, x2=None):
-    return ct_hip.linear_tokens(x, m.weight.detach(), None if m.bias is None else m.bias.detach(), act=act, x2=x2)
+    # the Parameter itself (not a detached alias): the pre-split bf16 image of the weight is cached on it
+    return ct_hip.linear_tokens(x, m.weight, m.bias, act=act, x2=x2)
 
 
 def _tokens(x):                                        # [B,C,H,W] -> [B,H*W,C]  (transformer.py:238-239)

@@ -282,6 +282,12 @@ int ct_eltwise_f32(const float *a, const float *b, const float *c, float *y, lon
  *   front of the FFN (transformer.py:131) without materialising it.                                               */
 int ct_linear_tokens_f32(const float *x, const float *x2, int k1, const float *w, const float *bias, float *out,
                          long long tokens, int k, int n, int act, void *stream);
+/* the same layer on the bf16 matrix pipe with float32-grade accuracy (operands as three bf16 pieces, six MFMAs per product;
+ *   csrc/conv_split.hip's arithmetic): wp = the weight pre-split on the host as bf16 bit patterns
+ *   [ceil(n/128)][k/32][piece hi/mid/lo][8-channel group 0..3][feature row 0..127][8 channels], zero rows beyond n
+ *   (ct_hip.pack_linear_weight_split).  k % 32 == 0.                                                              */
+int ct_linear_tokens_split_f32(const float *x, const float *x2, int k1, const void *wp, const float *bias, float *out,
+                               long long tokens, int k, int n, int act, void *stream);
 /* LayerNorm(128, eps 1e-5, affine) on tokens, out = residual + LN(x) when residual != NULL (transformer.py:139-147) */
 int ct_layernorm128_f32(const float *x, const float *gamma, const float *beta, const float *residual,
                         float *out, long long tokens, void *stream);

@@ -119,18 +119,40 @@ def test_eltwise(hip):
     close(hip.eltwise(5, a.cuda(), plane=35, chans=6, split=3), torch.cat([torch.tanh(a[:, :3]), torch.relu(a[:, 3:])], 1), "tanh|relu")
 
 
-@pytest.mark.parametrize("t,k,n,act", [(200, 128, 128, 0), (1000, 256, 1024, 6), (77, 1024, 128, 0), (33, 128, 128, 0)])
-def test_linear_tokens(hip, t, k, n, act):
+@pytest.mark.parametrize("mode", ["split", "exact"])
+@pytest.mark.parametrize("t,k,n,act", [(200, 128, 128, 0), (1000, 256, 1024, 6), (77, 1024, 128, 0), (33, 128, 128, 0), (300, 160, 200, 6),
+                                       (129, 32, 2, 0), (4000, 128, 384, 0)])
+def test_linear_tokens(hip, t, k, n, act, mode):
+    """both arithmetic paths of nn.Linear on tokens (float32 MFMA / three-piece bf16 split, six MFMAs per product) against
+    float64 torch -- the split path is held to the same float32-rounding-level bound"""
     x, w, b = rnd(t, k), rnd(n, k) / k ** 0.5, rnd(n)
     ref = F.linear(x.double(), w.double(), b.double())
     if act == 6:
         ref = F.gelu(ref)
-    close(hip.linear_tokens(x.cuda(), w.cuda(), b.cuda(), act=act), ref, "linear")
-    close(hip.linear_tokens(x.cuda(), w.cuda(), None, act=0), F.linear(x.double(), w.double()), "linear nobias")
+    wc = w.cuda()
+    close(hip.linear_tokens(x.cuda(), wc, b.cuda(), act=act, mode=mode), ref, "linear")
+    close(hip.linear_tokens(x.cuda(), wc, None, act=0, mode=mode), F.linear(x.double(), w.double()), "linear nobias")
     if k >= 64:                                    # [x[:, :k1] | x[:, k1:]] from two tensors == linear on the concatenation
         k1 = 32 * (k // 64)
         xa, xb = x[:, :k1].contiguous().cuda(), x[:, k1:].contiguous().cuda()
-        close(hip.linear_tokens(xa, w.cuda(), b.cuda(), act=act, x2=xb), ref, "linear on a two-source row")
+        close(hip.linear_tokens(xa, wc, b.cuda(), act=act, x2=xb, mode=mode), ref, "linear on a two-source row")
+    if mode == "split":                            # the pre-split weight is cached on the tensor and follows in-place updates
+        assert wc._ct_lin_split[1].shape == ((n + 127) // 128, k // 32, 3, 4, 128, 8)
+        wc.mul_(2.0)
+        close(hip.linear_tokens(x.cuda(), wc, None, mode=mode), 2 * F.linear(x.double(), w.double()), "repacked after an in-place update")
+
+
+def test_linear_tokens_split_wide_dynamic_range(hip):
+    """split-path accuracy does not depend on operand magnitude: rows scaled by 2^-20 .. 2^20 keep the relative error of a
+    float32 dot product (the three bf16 pieces carry 24 mantissa bits at any exponent)"""
+    t, k, n = 512, 256, 128
+    x, w = rnd(t, k), rnd(n, k) / 16
+    scale = torch.pow(2.0, torch.randint(-20, 21, (t, 1), generator=G).float())
+    xs = x * scale
+    ref = F.linear(xs.double(), w.double())
+    out = hip.linear_tokens(xs.cuda(), w.cuda(), None, mode="split").cpu().double()
+    bound = F.linear(xs.double().abs(), w.double().abs())            # sum |x||w|: the natural error scale of a dot product
+    assert ((out - ref).abs() / bound).max().item() < 4e-7
 
 
 def test_layernorm(hip):
