@@ -280,6 +280,12 @@ def main():
             pm = os.path.join(ROOT, "profiles", "r02_gmflow_960x540_mfma_pmc.json")
             if os.path.exists(pm):
                 extra["gmflow_960x540_mfma_busy_time_weighted"] = json.load(open(pm)).get("_all_kernels", {}).get("mfma_busy_frac_time_weighted")
+            # configs[3] whole: DMSCT.forward (matcher + EfficientNet-B2 encoder on both views + fusion + U-Net decoder + head), random init
+            dm = DMSCT().to(device).eval()
+            dm.matcher = gm
+            t960, r960 = a960 / 255, b960 / 255
+            extra["dmsct_960x540_pairs_per_s_f32"] = rate(lambda: dm(t960, r960), n=3)
+            del dm
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -47,6 +47,7 @@ __device__ __forceinline__ float conv_act(float v, int act) {
         case 2: return v > 0.f ? v : 0.f;
         case 3: return 1.0f / (1.0f + expf(-v));
         case 4: return tanhf(v);
+        case 5: return v / (1.0f + expf(-v));        // swish
         default: return v;
     }
 }

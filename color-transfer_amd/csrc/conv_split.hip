@@ -36,6 +36,7 @@ __device__ __forceinline__ float split_act(float v, int act) {
         case 2: return v > 0.f ? v : 0.f;
         case 3: return 1.0f / (1.0f + expf(-v));
         case 4: return tanhf(v);
+        case 5: return v / (1.0f + expf(-v));        // swish
         default: return v;
     }
 }
@@ -470,7 +471,7 @@ extern "C" {
 int ct_conv2d_split_f32(const float *in, const float *in2, int cin1, const void *wp_split, const float *bias, const float *residual,
                         float *out, int n, int cin, int cout, int h, int w, int kh, int kw, long long in_bstride,
                         long long in2_bstride, long long out_bstride, long long res_bstride, int act, int clamp, void *stream) {
-    if (!in || !wp_split || !bias || !out || n < 0 || cin < 1 || cout < 1 || h < 0 || w < 0 || act < 0 || act > 4) return CT_E_BADARG;
+    if (!in || !wp_split || !bias || !out || n < 0 || cin < 1 || cout < 1 || h < 0 || w < 0 || act < 0 || act > 5) return CT_E_BADARG;
     if (in2 && (cin1 < 16 || cin1 >= cin || (cin1 % 16))) return CT_E_BADARG;
     if (n == 0 || h == 0 || w == 0) return CT_OK;
     ct::ConvArgs a;

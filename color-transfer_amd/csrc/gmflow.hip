@@ -30,7 +30,7 @@ struct GConvArgs {
     float *out;
     int cin, cout, coutp, H, W, Ho, Wo, KH, KW, stride, padH, padW;
     long long in_bstride, out_bstride;
-    int act;      // 0 none, 1 LeakyReLU(0.01), 2 ReLU, 3 sigmoid, 4 tanh
+    int act;      // 0 none, 1 LeakyReLU(0.01), 2 ReLU, 3 sigmoid, 4 tanh, 5 swish
     int cchunk;   // input channels staged per LDS pass (even)
 };
 
@@ -40,6 +40,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         case 2: return v > 0.f ? v : 0.f;
         case 3: return 1.0f / (1.0f + expf(-v));
         case 4: return tanhf(v);
+        case 5: return v / (1.0f + expf(-v));        // swish (efficientnet_pytorch MemoryEfficientSwish)
         default: return v;
     }
 }
@@ -1451,6 +1452,36 @@ int ct_gconv2d_f32(const float *in, const float *wp, const float *bias, float *o
     const int tiles_x = (a.Wo + 31) / 32, tiles_y = (a.Ho + 3) / 4;
     dim3 grid(tiles_x * tiles_y, a.coutp / 64, n);
     hipLaunchKernelGGL(ct::conv_generic_kernel, grid, dim3(256), lds, (hipStream_t)stream, a, tiles_x, tiles_y);
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+}
+
+// The generic convolution with explicit top / left zero padding and output size (bottom / right padding is whatever the
+// output size implies) -- TF-"SAME" static padding of efficientnet_pytorch's stride-2 stem: pad (0, 1).
+int ct_gconv2d_pad_f32(const float *in, const float *wp, const float *bias, float *out, int n, int cin, int cout, int h, int w, int kh,
+                       int kw, int stride, int pad_top, int pad_left, int out_h, int out_w, long long in_bstride, long long out_bstride,
+                       int act, void *stream) {
+    if (!in || !wp || !out || n < 0 || cin < 1 || cout < 1 || h < 1 || w < 1 || kh < 1 || kw < 1 || stride < 1 || pad_top < 0 ||
+        pad_left < 0 || out_h < 1 || out_w < 1)
+        return CT_E_BADARG;
+    if ((out_h - 1) * stride - pad_top >= h || (out_w - 1) * stride - pad_left >= w) return CT_E_BADARG;
+    if (n == 0) return CT_OK;
+    ct::GConvArgs a;
+    a.in = in; a.wp = wp; a.bias = bias; a.out = out;
+    a.cin = cin; a.cout = cout; a.coutp = 64 * ((cout + 63) / 64);
+    a.H = h; a.W = w; a.KH = kh; a.KW = kw; a.stride = stride; a.padH = pad_top; a.padW = pad_left;
+    a.Ho = out_h; a.Wo = out_w;
+    a.in_bstride = in_bstride; a.out_bstride = out_bstride; a.act = act;
+    const int TR = 3 * stride + kh, TC = 31 * stride + kw;
+    int cchunk = (48 * 1024) / (TR * TC * 4);
+    cchunk &= ~1;
+    if (cchunk > 32) cchunk = 32;
+    if (cchunk < 2) return CT_E_BADARG;
+    a.cchunk = cchunk;
+    const size_t lds = (size_t)cchunk * TR * TC * sizeof(float);
+    const int tiles_x = (a.Wo + 31) / 32, tiles_y = (a.Ho + 3) / 4;
+    hipLaunchKernelGGL(ct::conv_generic_kernel, dim3(tiles_x * tiles_y, a.coutp / 64, n), dim3(256), lds, (hipStream_t)stream, a, tiles_x,
+                       tiles_y);
     CT_CHECK_LAUNCH();
     return CT_OK;
 }

@@ -650,11 +650,14 @@ def pack_gconv_weight(weight, bias):
     return wp, b
 
 
-def gconv2d(x, wp, bias, cout, ksize, stride=1, padding=0, act=ACT_NONE, out=None, x2=None):
+def gconv2d(x, wp, bias, cout, ksize, stride=1, padding=0, act=ACT_NONE, out=None, x2=None, residual=None):
     """x2: optional second input tensor whose channels follow x's (torch.cat([x, x2], 1) without the copy when the
-    split-bf16 kernel takes the convolution; otherwise the concatenation is materialised here)."""
+    split-bf16 kernel takes the convolution; otherwise the concatenation is materialised here).  residual: added to the
+    result (act must be ACT_NONE: MBConvBlock's identity skip)."""
     kh, kw = (ksize, ksize) if isinstance(ksize, int) else ksize
     ph, pw = (padding, padding) if isinstance(padding, int) else padding
+    if residual is not None and (act != ACT_NONE or x2 is not None):
+        raise CtHipError("gconv2d: a residual needs act=ACT_NONE and a single input")
     if x2 is not None:
         split = getattr(wp, "_ct_split", None)
         n, c1, h, w = x.shape
@@ -669,10 +672,12 @@ def gconv2d(x, wp, bias, cout, ksize, stride=1, padding=0, act=ACT_NONE, out=Non
     if out is None:
         out = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device)
     split = getattr(wp, "_ct_split", None)
-    if split is not None and bias is not None and _split_ok(x, out, None, kh, kw, stride, ph, pw):
-        return _conv_split(x, split, cout, kh, kw, act, None, False, out)
+    if split is not None and bias is not None and _split_ok(x, out, residual, kh, kw, stride, ph, pw):
+        return _conv_split(x, split, cout, kh, kw, act, residual, False, out)
     check(lib().ct_gconv2d_f32(_ptr(x), _ptr(wp), _opt(bias), _ptr(out), n, cin, cout, h, w, kh, kw, stride, ph, pw,
                                _nchw_bstride(x), _nchw_bstride(out), int(act), _stream()))
+    if residual is not None:
+        return eltwise(0, out, residual)
     return out
 
 
@@ -691,6 +696,73 @@ def eltwise(op, a, b=None, c=None, plane=1, chans=1, split=0, s0=1.0):
     y = torch.empty_like(a)
     check(lib().ct_eltwise_f32(_ptr(a), _opt(b), _opt(c), _ptr(y), a.numel(), op, plane, chans, split, float(s0), _stream()))
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# f4: layers of DMSCT's EfficientNet-B2 / U-Net (csrc/unet.hip)
+# ------------------------------------------------------------------------------------------------
+ACT_SWISH = 5
+SIGNATURES.update({
+    "ct_gconv2d_pad_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 12 + [_c_ll, _c_ll, _c_int, _c_p]),
+    "ct_dwconv_tiles": (_c_int, [_c_int, _c_int]),
+    "ct_dwconv_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 11 + [_c_p, _c_p]),
+    "ct_se_gate_f32": (_c_int, [_c_p, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
+    "ct_scale_planes_f32": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_p]),
+    "ct_upsample2_concat_f32": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
+})
+
+
+def gconv2d_pad(x, wp, bias, cout, ksize, stride, pad_top_left, out_size, act=ACT_NONE):
+    """generic convolution with explicit (top, left) zero padding and output size (TF-"SAME" static padding)"""
+    _f32c(x)
+    n, cin, h, w = x.shape
+    out = torch.empty((n, cout, out_size[0], out_size[1]), dtype=torch.float32, device=x.device)
+    check(lib().ct_gconv2d_pad_f32(_ptr(x), _ptr(wp), _opt(bias), _ptr(out), n, cin, cout, h, w, ksize, ksize, stride, pad_top_left[0],
+                                   pad_top_left[1], out_size[0], out_size[1], _nchw_bstride(x), _nchw_bstride(out), int(act), _stream()))
+    return out
+
+
+def dwconv(x, weight, bias, ksize, stride, pad_top_left, out_size, act=ACT_SWISH, want_sums=False):
+    """depthwise convolution, weight [C, k*k] and bias [C] with the BatchNorm folded in; -> out (, tile sums [N, C, tiles])"""
+    _f32c(x, weight, bias)
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, out_size[0], out_size[1]), dtype=torch.float32, device=x.device)
+    sums = None
+    if want_sums:
+        sums = torch.empty((n, c, lib().ct_dwconv_tiles(out_size[0], out_size[1])), dtype=torch.float32, device=x.device)
+    check(lib().ct_dwconv_f32(_ptr(x), _ptr(weight), _ptr(bias), _ptr(out), n, c, h, w, ksize, stride, pad_top_left[0], pad_top_left[1],
+                              out_size[0], out_size[1], int(act), _opt(sums), _stream()))
+    return (out, sums) if want_sums else out
+
+
+def se_gate(tile_sums, plane, w_reduce, b_reduce, w_expand, b_expand):
+    """squeeze-and-excitation gate [N, C] from the tile sums of the depthwise output"""
+    _f32c(tile_sums, w_reduce, b_reduce, w_expand, b_expand)
+    n, c, tiles = tile_sums.shape
+    gate = torch.empty((n, c), dtype=torch.float32, device=tile_sums.device)
+    check(lib().ct_se_gate_f32(_ptr(tile_sums), tiles, plane, _ptr(w_reduce), _ptr(b_reduce), _ptr(w_expand), _ptr(b_expand), _ptr(gate),
+                               n, c, w_reduce.shape[0], _stream()))
+    return gate
+
+
+def scale_planes_(x, gate):
+    """x[n, c] *= gate[n, c] in place"""
+    _f32c(x, gate)
+    n, c, h, w = x.shape
+    check(lib().ct_scale_planes_f32(_ptr(x), _ptr(gate), n * c, h * w, _stream()))
+    return x
+
+
+def upsample2_concat(x, skip=None):
+    """cat([nearest-x2(x), skip], dim=1)"""
+    _f32c(x, skip)
+    n, cx, h, w = x.shape
+    cs = 0 if skip is None else skip.shape[1]
+    if skip is not None and tuple(skip.shape) != (n, cs, 2 * h, 2 * w):
+        raise CtHipError("upsample2_concat: skip must be [N, Cs, 2H, 2W]")
+    out = torch.empty((n, cx + cs, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+    check(lib().ct_upsample2_concat_f32(_ptr(x), _opt(skip), _ptr(out), n, cx, cs, h, w, _stream()))
+    return out
 
 
 def pack_linear_weight_split(weight):

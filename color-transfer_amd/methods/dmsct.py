@@ -1,8 +1,9 @@
-"""DMSCT ("ours" of the reference, methods/dmsct.py:19-116) -- the part of its forward that can be pinned offline.
+"""DMSCT ("ours" of the reference, methods/dmsct.py:19-116): forward pass on HIP kernels.
 
 DMSCT = frozen GMFlow matcher + `segmentation_models_pytorch` EfficientNet-B2 encoder / U-Net decoder /
-segmentation head.  smp is an un-vendored third-party dependency that is absent offline, so its arithmetic has no
-oracle here ("parity unpinned"); everything AROUND it is implemented on HIP kernels:
+segmentation head.  smp is an un-vendored third-party dependency that is absent offline: `smp_hip` implements those
+three modules (same module tree and parameter names, HIP forward) against a restatement of their published structure
+("parity unpinned", oracle/smp_unet.py).  Everything around them is pinned by reference-run fixtures:
 
   * the matcher call exactly as the reference makes it (dmsct.py:85-94): `unimatch.GMFlow` on `target*255`,
     `reference*255`, `derive_matcher_inference_size`, bidirectional flow + forward-backward occlusion;
@@ -10,13 +11,15 @@ oracle here ("parity unpinned"); everything AROUND it is i
     bilinear flow rescale, `flow_warp` of the reference features, nearest-resized `1 - fwd_occ`, concatenation;
   * the residual output (dmsct.py:116): `clamp(target + head(decoder(*features))[:, :, :H, :W], 0, 1)`.
 
-`DMSCT(encoder=..., decoder=..., head=...)` accepts any torch modules with smp's calling convention (encoder(x) ->
-list of feature maps at strides 1,2,4,...; decoder(*features); head(x)); without them `forward` raises.
+Constructor arguments as in the reference (dmsct.py:20-25); `encoder=`, `decoder=`, `head=` optionally replace the
+smp_hip modules by any torch modules with smp's calling convention (encoder(x) -> list of feature maps at strides
+1,2,4,...; decoder(*features); head(x)).  Inference only (the reference's training step is out of scope).
 """
 import numpy as np
 import torch
 
 import ct_hip
+import smp_hip
 from unimatch import GMFlow
 
 
@@ -29,6 +32,14 @@ class DMSCT(torch.nn.Module):
         self.matcher = GMFlow(matcher_weights)
         for p in self.matcher.parameters():
             p.requires_grad = False                       # dmsct.py:30-32
+        if encoder is None:                               # dmsct.py:34-38
+            encoder = smp_hip.get_encoder(name=encoder_name, depth=encoder_depth, weights=encoder_weights)
+        if decoder is None:                               # dmsct.py:40-51: every scale carries [f_t | warped f_r | 1 - occ]
+            channels = [2 * c + 1 for c in encoder.out_channels]
+            decoder = smp_hip.UnetDecoder(encoder_channels=channels, decoder_channels=decoder_channels, n_blocks=encoder_depth,
+                                          use_batchnorm=False)
+        if head is None:                                  # dmsct.py:53-56
+            head = smp_hip.SegmentationHead(in_channels=decoder_channels[-1], out_channels=3)
         self.encoder, self.decoder, self.head = encoder, decoder, head
 
     @staticmethod
@@ -73,9 +84,6 @@ class DMSCT(torch.nn.Module):
         return out
 
     def forward(self, target, reference):
-        if self.encoder is None or self.decoder is None or self.head is None:
-            raise NotImplementedError("DMSCT's encoder/decoder/head come from segmentation_models_pytorch, which is not "
-                                      "available offline; pass modules with smp's calling convention")
         m = self.match(target, reference)
         _, _, height, width = reference.shape
         pad_size = self.derive_pad_size(reference.shape)
@@ -84,3 +92,12 @@ class DMSCT(torch.nn.Module):
         fr = self.encoder(pad(reference, pad_size, mode="replicate"))
         features = self.fuse_features(m["flow"], m["fwd_occ"], ft, fr, pad_size)
         return torch.clamp(target + self.head(self.decoder(*features))[:, :, :height, :width], min=0, max=1)
+
+    @torch.no_grad()
+    def test_step(self, batch, batch_idx=0, dataloader_idx=0):
+        """dmsct.py:118-131,139-140 (`step(batch, "Test")`): the per-batch metrics the reference logs -- PSNR, SSIM, iCID on the
+        device (FSIM, a piq metric, is not implemented; the losses are training quantities)."""
+        from methods import icid, psnr, ssim
+        result = self(batch["target"], batch["reference"])
+        gt = batch["gt"].to(result.device)
+        return {"Test PSNR": psnr(result, gt), "Test SSIM": ssim(result, gt), "Test iCID": icid(result, gt)}

@@ -232,7 +232,7 @@ int ct_conv2d_f32(const float *in, const float *wp, const float *bias, const flo
  * ct_conv2d_f32).  Stride 1, padding k/2, kernel (kh,kw) in {3x3, 1x1, 1x5, 5x1}; w % 4 == 0; in / out / residual
  * 16-byte aligned with batch strides % 4 == 0 (CT_E_BADARG otherwise: use ct_conv2d_f32 / ct_gconv2d_f32 then).
  * wp_split: bf16 bit patterns [ceil(cout/64)][ceil(cin/16)][kh*kw][piece hi,mid,lo][m][k-half][cout%32][8 channels];
- * bias: zero padded to 64*ceil(cout/64).  act: 0 none, 1 LeakyReLU(0.01), 2 ReLU, 3 sigmoid, 4 tanh.
+ * bias: zero padded to 64*ceil(cout/64).  act: 0 none, 1 LeakyReLU(0.01), 2 ReLU, 3 sigmoid, 4 tanh, 5 swish.
  * in2 != NULL: input channels [cin1, cin) come from in2 (cin1 % 16 == 0) -- torch.cat([a, b], dim=1) without the copy
  * (reg_refine.py:43,72,75: the GRU's hx / [r*h, x] and the motion encoder's [cor, flo]).                            */
 int ct_conv2d_split_f32(const float *in, const float *in2, int cin1, const void *wp_split, const float *bias,
@@ -342,6 +342,33 @@ int ct_convex_upsample_f32(const float *flow, const float *mask, float *out, int
 int ct_fb_check_f32(const float *fwd, const float *bwd, const float *warped_bwd, const float *warped_fwd,
                     float *fwd_occ, float *bwd_occ, int b, int h, int w, float alpha, float beta,
                     void *stream);
+
+/* ---- f4: DMSCT's colour-correction network (methods/dmsct.py:34-56,96-116): segmentation_models_pytorch's EfficientNet-B2
+ * encoder (efficientnet_pytorch MBConv blocks), UnetDecoder and SegmentationHead.  Third-party, absent offline: the
+ * structure is restated in oracle/smp_unet.py ("parity unpinned").  float32 NCHW.  The 1x1 / 3x3 convolutions of these
+ * layers are ct_gconv2d_f32 / ct_conv2d_split_f32 with the BatchNorm folded into weight and bias (act 5 = swish).
+ *
+ * ct_gconv2d_pad_f32: ct_gconv2d_f32's generic kernel with explicit top / left zero padding and output size (the bottom /
+ *   right padding is what the output size implies): efficientnet_pytorch's static TF-"SAME" padding, e.g. (0, 1) for the
+ *   stride-2 stem (Conv2dStaticSamePadding).
+ * ct_dwconv_f32: depthwise k x k convolution (k 3 / 5, stride 1 / 2), same padding convention, BatchNorm folded into
+ *   w [c][k*k] and bias [c], act 0 / 5 (`swish(bn1(depthwise_conv(x)))`, MBConvBlock.forward).  tile_sums (nullable):
+ *   [n][c][ct_dwconv_tiles(out_h, out_w)] receives the sum of every output tile -- the squeeze of the SE gate.
+ * ct_se_gate_f32: gate[n][c] = sigmoid(se_expand(swish(se_reduce(mean)))) with mean = sum(tile_sums) / plane (float64,
+ *   fixed order); w_reduce [nsq][c], w_expand [c][nsq].
+ * ct_scale_planes_f32: x[p][:] *= gate[p], in place (`torch.sigmoid(x_squeezed) * x`).
+ * ct_upsample2_concat_f32: DecoderBlock.forward's `cat([interpolate(x, scale_factor=2, mode="nearest"), skip], 1)`.    */
+int ct_gconv2d_pad_f32(const float *in, const float *wp, const float *bias, float *out, int n, int cin, int cout, int h,
+                       int w, int kh, int kw, int stride, int pad_top, int pad_left, int out_h, int out_w,
+                       long long in_bstride, long long out_bstride, int act, void *stream);
+int ct_dwconv_tiles(int out_h, int out_w);
+int ct_dwconv_f32(const float *in, const float *w, const float *bias, float *out, int n, int c, int h, int wd, int k,
+                  int stride, int pad_top, int pad_left, int out_h, int out_w, int act, float *tile_sums, void *stream);
+int ct_se_gate_f32(const float *tile_sums, int tiles, int plane, const float *w_reduce, const float *b_reduce,
+                   const float *w_expand, const float *b_expand, float *gate, int n, int c, int nsq, void *stream);
+int ct_scale_planes_f32(float *x, const float *gate, int planes, int plane, void *stream);
+int ct_upsample2_concat_f32(const float *x, const float *skip, float *out, int n, int cx, int cs, int h, int w,
+                            void *stream);
 
 #ifdef __cplusplus
 }

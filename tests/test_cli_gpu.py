@@ -48,6 +48,31 @@ def test_cli_dcmcs3di(capsys):
     assert table.shape == (2, 3) and torch.isfinite(table).all()
 
 
+def test_cli_dmsct_with_checkpoint(tmp_path, capsys):
+    """configs/dmsct.yaml through utils.cli: DMSCT with its default smp_hip modules, weights from a Lightning-style checkpoint
+    ({"state_dict": ...} with the reference's parameter names, loaded strictly)."""
+    from utils import cli
+    from methods.dmsct import DMSCT
+    torch.manual_seed(1)
+    ref_model = DMSCT()
+    with torch.no_grad():
+        ref_model.head[0].weight.mul_(0.1)
+    ckpt = os.path.join(tmp_path, "dmsct.ckpt")
+    torch.save({"state_dict": ref_model.state_dict(), "hyper_parameters": {"encoder_name": "efficientnet-b2"}}, ckpt)
+    args = ["test", "--config", os.path.join(CFG, "dmsct.yaml"), "--ckpt_path", ckpt, "--data.n_frames", "2", "--data.height", "128",
+            "--data.width", "192"]
+    table = cli.main(args)
+    assert table.shape == (2, 3) and torch.isfinite(table).all()
+    assert "Test PSNR" in capsys.readouterr().out
+    assert torch.equal(table, cli.main(args))                                     # deterministic, weights come from the file
+    # the table is what the loaded model computes
+    from utils.data import SyntheticStereoFrames
+    fr = SyntheticStereoFrames(2, 128, 192)
+    batch = {k: fr[1][k][None].cuda() for k in ("target", "reference", "gt")}
+    m = ref_model.cuda().eval().test_step(batch)
+    assert abs(float(m["Test PSNR"]) - float(table[1, 0])) < 1e-9
+
+
 def test_frame_psnr_kernel():
     import ct_hip
     gen = torch.Generator().manual_seed(0)
