@@ -231,6 +231,9 @@ def main():
             idt = B * rate(lambda: it.iterative_distribution_transfer_cuda(tgt, ref, rotations=rots, out=idt_out), n=10)
             extra["idt_pairs_per_s_f64"] = idt                           # B pairs per call, like the headline
             extra["idt_frac_hbm_peak"] = 920678400 * idt / HBM_PEAK      # float64 working image
+            # bytes the kernels actually move per pair: float32 frames are read as float32 (min/max x2, histogram of iteration
+            # 0, reference in every histogram, apply 0 input) = 8 float32 planes of 24.9 MB + 10 float64 planes of 49.8 MB
+            extra["idt_frac_hbm_peak_bytes_moved"] = (8 * 4 + 10 * 8) * 3 * H * W * idt / HBM_PEAK
             del idt_out
             # configs[2]: DCMCS3DI forward, random init, 512x512.  The convolutions run float32 operands as three bf16
             # pieces with six bf16 MFMAs per product (float32-grade accuracy, csrc/conv_split.hip); rates are quoted in

@@ -121,7 +121,8 @@ def test_dmsct_glue_vs_oracle(golden_dir):
 
 
 def test_dmsct_forward_with_injected_modules():
-    """End to end with stand-in encoder/decoder/head modules (smp's calling convention), and the loud failure without."""
+    """End to end with stand-in encoder/decoder/head modules (smp's calling convention); without them DMSCT builds its
+    EfficientNet-B2 / U-Net modules like the reference (tests/test_smp_unet_gpu.py)."""
     from methods.dmsct import DMSCT
 
     class Enc(torch.nn.Module):
@@ -139,5 +140,5 @@ def test_dmsct_forward_with_injected_modules():
     t, r = torch.rand(1, 3, 70, 100).cuda(), torch.rand(1, 3, 70, 100).cuda()
     out = DMSCT(encoder=Enc(), decoder=Dec(), head=Head()).cuda()(t, r)
     assert out.shape == t.shape and out.min() >= 0 and out.max() <= 1 and torch.isfinite(out).all()
-    with pytest.raises(NotImplementedError):
-        DMSCT().cuda()(t, r)
+    out = DMSCT().cuda()(t, r)
+    assert out.shape == t.shape and out.min() >= 0 and out.max() <= 1 and torch.isfinite(out).all()

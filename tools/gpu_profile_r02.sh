@@ -17,6 +17,7 @@ rocprofv3 --kernel-trace --pmc $M --output-format csv -d $OUT/mfma_dc1080 -- pyt
 rocprofv3 --kernel-trace --pmc $M --output-format csv -d $OUT/mfma_gm960 -- python3 $ROOT/tools/bench_gmflow.py 540 960 2 > $OUT/mfma_gm960.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_dc1080 -- python3 $ROOT/tools/bench_dcmcs3di.py 1080 1920 3 > $OUT/trace_dc1080.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_gm960 -- python3 $ROOT/tools/bench_gmflow.py 540 960 3 > $OUT/trace_gm960.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_dmsct960 -- python3 $ROOT/tools/bench_dmsct.py 540 960 3 > $OUT/trace_dmsct960.txt 2>&1
 cd $ROOT
 # keep what is small enough to travel back (the raw traces of the CNN runs are large)
 find $OUT -name "*kernel_trace.csv" -size +20M -delete
