@@ -10,16 +10,23 @@ SRC = os.path.join(ROOT, "gpurun_out", "prof_r02")
 DST = os.path.join(ROOT, "profiles")
 
 
+def newest(sub, pattern):
+    """gpurun merges a call's files INTO the local gpurun_out/: an earlier call's outputs may still lie beside the new ones"""
+    f = glob.glob(os.path.join(SRC, sub, "**", pattern), recursive=True)
+    return max(f, key=os.path.getmtime) if f else None
+
+
 def stats_csv(sub, name):
-    f = glob.glob(os.path.join(SRC, sub, "**", "*kernel_stats.csv"), recursive=True)
+    f = newest(sub, "*kernel_stats.csv")
     if f:
-        shutil.copy(f[0], os.path.join(DST, name))
+        shutil.copy(f, os.path.join(DST, name))
         print("wrote", name)
 
 
 def counters(sub):
     agg = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
-    for f in glob.glob(os.path.join(SRC, sub, "**", "*counter_collection.csv"), recursive=True):
+    f = newest(sub, "*counter_collection.csv")
+    if f:
         for row in csv.DictReader(open(f)):
             a = agg[row["Kernel_Name"]][row["Counter_Name"]]
             a[0] += float(row["Counter_Value"]); a[1] += 1
