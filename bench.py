@@ -9,7 +9,7 @@ synthetic 1920x1080 float32 RGB pairs, inputs resident in HBM, `--pairs` pairs p
 (one step = one ct_reinhard_f32 call -- statistics sweep over 2*pairs images, apply sweep with
 the statistics finished in its prologue -- plus the per-frame metric of Runner.test_step,
 ct_frame_psnr_f32 of the corrected frames against resident ground-truth frames; `--metrics
-psnr,ssim,icid` adds the other two).  Frames shard across ranks (frame f -> rank f % world);
+psnr,ssim,fsim,icid` adds the others).  Frames shard across ranks (frame f -> rank f % world);
 the [frames, n_metrics] table is gathered with ONE RCCL all_gather at the end of the timed
 region (configs[4]).  `value` = all ranks' pairs / max-over-ranks wall time.
 
@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--pairs", type=int, default=4, help="stereopairs per step per GPU")
-    ap.add_argument("--metrics", default="psnr", help="per-frame metrics inside the timed region: psnr[,ssim,icid] or none")
+    ap.add_argument("--metrics", default="psnr", help="per-frame metrics inside the timed region: psnr[,ssim,fsim,icid] or none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
@@ -100,12 +100,12 @@ def main():
 
     B, K, Wm = args.pairs, args.steps, args.warmup
     names = [m for m in args.metrics.split(",") if m and m != "none"]
-    assert all(m in ("psnr", "ssim", "icid") for m in names), names
+    assert all(m in ("psnr", "ssim", "fsim", "icid") for m in names), names
     # frames owned by this rank: f % world == rank; a ring of `B` resident pairs is re-used every step
     frame_ids = [rank + world * i for i in range(B)]
     tgt, ref, gt = synth_frames(frame_ids, device)
     out = torch.empty_like(tgt)
-    gt_nchw = gt.permute(0, 3, 1, 2).contiguous() if ("ssim" in names or "icid" in names) else None
+    gt_nchw = gt.permute(0, 3, 1, 2).contiguous() if any(m in names for m in ("ssim", "fsim", "icid")) else None
     n_m = max(len(names), 1)
     metrics = torch.zeros((K, B, n_m), dtype=torch.float64, device=device)      # this rank's [frames, n_metrics] table
     gathered = torch.empty((world,) + tuple(metrics.shape), dtype=torch.float64, device=device) if world > 1 else None
@@ -122,7 +122,7 @@ def main():
                 metrics[i, :, j] = ct_hip.frame_psnr(out, gt)[:, 1]            # layout-agnostic: HWC against HWC
             else:
                 o = out.permute(0, 3, 1, 2).contiguous()
-                metrics[i, :, j] = (ct_hip.frame_ssim if m == "ssim" else ct_hip.frame_icid)(o, gt_nchw)
+                metrics[i, :, j] = {"ssim": ct_hip.frame_ssim, "fsim": ct_hip.frame_fsim, "icid": ct_hip.frame_icid}[m](o, gt_nchw)
 
     def barrier():
         if world > 1:
@@ -227,6 +227,7 @@ def main():
             extra["frames_per_s_psnr"] = B * rate(lambda: ct_hip.frame_psnr(out, gt), n=100)
             extra["frames_per_s_ssim"] = B * rate(lambda: ct_hip.frame_ssim(o_nchw, g_nchw), n=100)
             extra["frames_per_s_icid"] = B * rate(lambda: ct_hip.frame_icid(o_nchw, g_nchw), n=100)
+            extra["frames_per_s_fsim"] = B * rate(lambda: ct_hip.frame_fsim(o_nchw, g_nchw), n=20)
             del o_nchw, g_nchw
             extra["mk_pairs_per_s_f64out_hostalgebra"] = rate(
                 lambda: lin.monge_kantorovitch_color_transfer_cuda(tgt[0], ref[0], host_algebra=True))

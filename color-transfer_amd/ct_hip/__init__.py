@@ -364,6 +364,52 @@ def frame_icid(a, b):
     return _frame_metric("ct_frame_icid_f32", a, b)
 
 
+SIGNATURES.update({
+    "ct_fsim_pooled_size": (_c_int, [_c_int, _c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "ct_fsim_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
+    "ct_fsim_setup_f32": (_c_int, [_c_int, _c_int, _c_p, _c_p, _c_p, _c_sz, _c_p]),
+    "ct_frame_fsim_f32": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_sz, _c_p]),
+})
+_fsim_tables = {}                                  # (device, h, w) -> (filters [16, hp*wp] float32, consts [4, 3] float64)
+CT_WS_FSIM = -7
+
+
+def _fsim_ws(device, batch, h, w):
+    need = lib().ct_fsim_workspace_bytes(batch, h, w)
+    if need == 0:
+        raise CtHipError("fsim: frames of %dx%d are too small (pooled size < 2)" % (h, w))
+    ws = workspace(CT_WS_FSIM, 0, batch, device, need=need + 256)
+    off = (-ws.data_ptr()) % 256
+    return ws[off:off + need]
+
+
+def frame_fsim(a, b):
+    """Per-frame piq.fsim(a, b) (chromatic, piq defaults, data range 1) of float32 [B,3,H,W] batches -> float64 [B]
+    (methods/__init__.py:34).  The filter bank of a frame size is built on the device at first use and cached."""
+    _require_cuda(a, b)
+    if a.shape != b.shape or a.dim() != 4 or a.shape[1] != 3 or a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise CtHipError("ct_frame_fsim_f32 needs two float32 [B,3,H,W] tensors of one shape")
+    B, _, h, w = a.shape
+    out = torch.empty((B,), dtype=torch.float64, device=a.device)
+    if B == 0:
+        return out
+    ws = _fsim_ws(a.device, B, h, w)
+    key = (str(a.device), h, w)
+    with _lock:
+        tab = _fsim_tables.get(key)
+    if tab is None:
+        hp, wp = ctypes.c_int(0), ctypes.c_int(0)
+        check(lib().ct_fsim_pooled_size(h, w, ctypes.byref(hp), ctypes.byref(wp)))
+        filters = torch.empty((16, hp.value * wp.value), dtype=torch.float32, device=a.device)
+        consts = torch.empty((4, 3), dtype=torch.float64, device=a.device)
+        check(lib().ct_fsim_setup_f32(h, w, _ptr(filters), _ptr(consts), _ptr(ws), ws.numel(), _stream()))
+        tab = (filters, consts)
+        with _lock:
+            _fsim_tables[key] = tab
+    check(lib().ct_frame_fsim_f32(_ptr(a), _ptr(b), _ptr(out), B, h, w, _ptr(tab[0]), _ptr(tab[1]), _ptr(ws), ws.numel(), _stream()))
+    return out
+
+
 def mk_coef(stats_t, stats_r, decomposition="MK"):
     """On-device 3x3 algebra of MK (methods/linear.py:108-118): rgb_meancov records -> affine3x3 coefficient records."""
     mode = {"MK": 0, "sqrt": 1, "cholesky": 2}[decomposition]

@@ -3,8 +3,8 @@
 `Runner(func_spec)` resolves a dotted path "pkg.mod.func" with importlib exactly like the reference
 (methods/__init__.py:14-16); `forward(batch)` applies it to every sample of the batch
 (methods/__init__.py:18-27) and `test_step` clamps and scores the result (methods/__init__.py:29-40):
-PSNR, SSIM and iCID per frame on the GPU (ct_frame_*_f32; piq / kornia / torchvision arithmetic restated, see
-oracle/metrics.py).  FSIM (piq's FFT-based phase congruency) is not implemented.
+PSNR, SSIM, FSIM and iCID per frame on the GPU (ct_frame_*_f32; piq / kornia / torchvision arithmetic restated, see
+oracle/metrics.py).
 
 If the resolved module also offers a device-resident variant `<func>_cuda`, the batch never leaves
 the GPU; otherwise the numpy callable is used through the same host round trip as the reference.
@@ -37,7 +37,13 @@ def icid(x, y):
     return ct_hip.frame_icid(x.float().contiguous(), y.float().contiguous())
 
 
-METRICS = ("Test PSNR", "Test SSIM", "Test iCID")
+def fsim(x, y):
+    """piq.fsim(x, y) with piq's defaults (chromatic), per sample [B] (GPU only: ct_frame_fsim_f32)."""
+    import ct_hip
+    return ct_hip.frame_fsim(x.float().contiguous(), y.float().contiguous())
+
+
+METRICS = ("Test PSNR", "Test SSIM", "Test FSIM", "Test iCID")        # what test_step logs, in its order (methods/__init__.py:37-40)
 
 
 class Runner(torch.nn.Module):
@@ -71,5 +77,5 @@ class Runner(torch.nn.Module):
         gt = batch["gt"].to(result.device)
         out = {"Test PSNR": psnr(result, gt)}
         if result.is_cuda:
-            out["Test SSIM"], out["Test iCID"] = ssim(result, gt), icid(result, gt)
+            out["Test SSIM"], out["Test FSIM"], out["Test iCID"] = ssim(result, gt), fsim(result, gt), icid(result, gt)
         return out

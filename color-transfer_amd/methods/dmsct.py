@@ -95,9 +95,9 @@ class DMSCT(torch.nn.Module):
 
     @torch.no_grad()
     def test_step(self, batch, batch_idx=0, dataloader_idx=0):
-        """dmsct.py:118-131,139-140 (`step(batch, "Test")`): the per-batch metrics the reference logs -- PSNR, SSIM, iCID on the
-        device (FSIM, a piq metric, is not implemented; the losses are training quantities)."""
-        from methods import icid, psnr, ssim
+        """dmsct.py:118-131,139-140 (`step(batch, "Test")`): the per-batch metrics the reference logs -- PSNR, SSIM, FSIM, iCID
+        on the device (the two losses are training quantities)."""
+        from methods import fsim, icid, psnr, ssim
         result = self(batch["target"], batch["reference"])
         gt = batch["gt"].to(result.device)
-        return {"Test PSNR": psnr(result, gt), "Test SSIM": ssim(result, gt), "Test iCID": icid(result, gt)}
+        return {"Test PSNR": psnr(result, gt), "Test SSIM": ssim(result, gt), "Test FSIM": fsim(result, gt), "Test iCID": icid(result, gt)}

@@ -4,7 +4,7 @@ A minimal look-alike of the reference's LightningCLI entry point (utils/cli.py:1
 `test` sub-command only (Lightning/jsonargparse are not part of this stack): YAML with `class_path/init_args`
 for model and data, dotted `--section.key value` overrides, `trainer.*` keys accepted and ignored.  Frames are
 sharded over ranks when launched with torch.distributed.run (frame f -> rank f % world) and the per-frame
-metrics (PSNR, SSIM, iCID: the reference's Test PSNR / Test SSIM / Test iCID) are gathered with ONE collective
+metrics (PSNR, SSIM, FSIM, iCID: the reference's Test PSNR / Test SSIM / Test FSIM / Test iCID) are gathered with ONE collective
 (utils/sharding.py); rank 0 prints their means.
 """
 import importlib
@@ -73,7 +73,7 @@ def main(argv=None):
     data_cfg["class_path"] = "utils.data.DataModule"
     frames = _instantiate(data_cfg).test_frames()
     mine = sh.frames_of_rank(len(frames), rank, world)
-    from methods import METRICS, icid, psnr, ssim
+    from methods import METRICS, fsim, icid, psnr, ssim
     from utils.data import prefetch
     rows = []
     for f, sample in prefetch(frames, mine, device):       # pinned double-buffered uploads on a second stream
@@ -84,9 +84,9 @@ def main(argv=None):
         else:                                   # CNN modules: forward(target, reference, inference=True)
             corrected, _ = model(batch["target"], batch["reference"], inference=True)
             corrected = corrected.clamp(0, 1)
-            rows.append(torch.stack([fn(corrected, batch["gt"]).reshape(()) for fn in (psnr, ssim, icid)]))
+            rows.append(torch.stack([fn(corrected, batch["gt"]).reshape(()) for fn in (psnr, ssim, fsim, icid)]))
     local = torch.stack(rows).double() if rows else torch.zeros((0, len(METRICS)), dtype=torch.float64, device=device)
-    table = sh.gather_frame_metrics(local, len(frames), rank, world)        # [n_frames, 3]: PSNR, SSIM, iCID per frame
+    table = sh.gather_frame_metrics(local, len(frames), rank, world)        # [n_frames, 4]: PSNR, SSIM, FSIM, iCID per frame
     if rank == 0:
         for i, name in enumerate(METRICS):
             print("%s: %.4f" % (name, float(table[:, i].mean())), end="   " if i + 1 < len(METRICS) else "")

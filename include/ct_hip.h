@@ -343,6 +343,18 @@ int ct_fb_check_f32(const float *fwd, const float *bwd, const float *warped_bwd,
                     float *fwd_occ, float *bwd_occ, int b, int h, int w, float alpha, float beta,
                     void *stream);
 
+/* piq.fsim(result, gt) of Runner.test_step (methods/__init__.py:34; FSIMc, piq defaults; third-party, restated: parity
+ *   unpinned).  ct_fsim_setup_f32 builds, once per frame size, the log-Gabor filter bank ([16][hp*wp] float32,
+ *   orientation-major; hp x wp = ct_fsim_pooled_size) and its three noise constants per orientation ([4][3] float64) on
+ *   the device; ct_frame_fsim_f32 scores `batch` frames [batch][3][h][w] in [0,1]: out[b] float64.  The 1 + 16 FFTs per
+ *   image run in hipFFT (plans cached per size inside the library, work area inside ws); ws: 256-byte aligned,
+ *   ct_fsim_workspace_bytes(batch, h, w).                                                                            */
+int ct_fsim_pooled_size(int h, int w, int *hp, int *wp);
+size_t ct_fsim_workspace_bytes(int batch, int h, int w);
+int ct_fsim_setup_f32(int h, int w, float *filters, double *consts, void *ws, size_t ws_bytes, void *stream);
+int ct_frame_fsim_f32(const float *a, const float *b, double *out, int batch, int h, int w, const float *filters,
+                      const double *consts, void *ws, size_t ws_bytes, void *stream);
+
 /* ---- f4: DMSCT's colour-correction network (methods/dmsct.py:34-56,96-116): segmentation_models_pytorch's EfficientNet-B2
  * encoder (efficientnet_pytorch MBConv blocks), UnetDecoder and SegmentationHead.  Third-party, absent offline: the
  * structure is restated in oracle/smp_unet.py ("parity unpinned").  float32 NCHW.  The 1x1 / 3x3 convolutions of these

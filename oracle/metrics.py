@@ -13,7 +13,14 @@ TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
           4/29) and torchvision.transforms.functional.gaussian_blur (kernel1d = normalised exp(-0.5 (x / sigma)^2) on
           linspace(-(k-1)/2, (k-1)/2, k), reflect padding, depth-wise conv).  tests/golden/make_golden_icid.py RUNS the
           reference's utils/icid.py with exactly these two restatements plugged in, so every line of icid.py itself is pinned.
+* `fsim`  piq.fsim(x, y) with piq's defaults (chromatic FSIMc, 4 scales x 4 orientations of log-Gabor filters, Kovesi's
+          phase congruency PC_2 with the median noise estimate, Scharr gradient magnitude), restated from piq/fsim.py
+          (`fsim`, `_construct_filters`, `_phase_congruency`, `_lowpassfilter`) and piq/functional (`get_meshgrid`,
+          `ifftshift`, `scharr_filter`, `gradient_map`, `similarity_map`, `rgb2yiq`).  piq is absent offline and there is
+          nothing in this image to anchor it on: PARITY UNPINNED.
 """
+import math
+
 import torch
 import torch.nn.functional as F
 
@@ -117,3 +124,103 @@ def icid(img1, img2):
     for m in maps[1:]:
         prod = prod * m
     return 1 - prod.mean()
+
+
+
+# ---- FSIM (piq/fsim.py) -------------------------------------------------------------------------------------------------
+def _meshgrid(size):                                               # piq.functional.get_meshgrid
+    def axis(n):
+        if n % 2:
+            return torch.arange(-(n - 1) / 2, n / 2, dtype=torch.float64) / (n - 1)
+        return torch.arange(-n / 2, n / 2, dtype=torch.float64) / n
+    return torch.meshgrid(axis(size[0]), axis(size[1]), indexing="ij")
+
+
+def _ifftshift(x):                                                 # piq.functional.ifftshift: roll by -(n // 2) on every axis
+    return torch.roll(x, shifts=[-(n // 2) for n in x.shape], dims=list(range(x.dim())))
+
+
+def fsim_filters(h, w, scales=4, orientations=4, min_length=6, mult=2, sigma_f=0.55, delta_theta=1.2):
+    """[orientations * scales, h, w] log-Gabor filter bank of piq's _construct_filters (orientation-major)"""
+    theta_sigma = math.pi / (orientations * delta_theta)
+    gx, gy = _meshgrid((h, w))
+    radius = torch.sqrt(gx ** 2 + gy ** 2)
+    theta = torch.atan2(-gy, gx)
+    radius, theta = _ifftshift(radius), _ifftshift(theta)
+    radius[0, 0] = 1
+    sintheta, costheta = torch.sin(theta), torch.cos(theta)
+    lx, ly = _meshgrid((h, w))
+    lp = _ifftshift(1.0 / (1.0 + (torch.sqrt(lx ** 2 + ly ** 2) / 0.45) ** (2 * 15)))        # _lowpassfilter(cutoff=.45, n=15)
+    log_gabor = []
+    for s_ in range(scales):
+        omega_0 = 1.0 / (min_length * mult ** s_)
+        g = torch.exp((-torch.log(radius / omega_0) ** 2) / (2 * math.log(sigma_f) ** 2)) * lp
+        g[0, 0] = 0
+        log_gabor.append(g)
+    spread = []
+    for o in range(orientations):
+        angl = o * math.pi / orientations
+        ds = sintheta * math.cos(angl) - costheta * math.sin(angl)
+        dc = costheta * math.cos(angl) + sintheta * math.sin(angl)
+        dtheta = torch.abs(torch.atan2(ds, dc))
+        spread.append(torch.exp((-dtheta ** 2) / (2 * theta_sigma ** 2)))
+    spread, log_gabor = torch.stack(spread), torch.stack(log_gabor)
+    return spread.repeat_interleave(scales, dim=0) * log_gabor.repeat(orientations, 1, 1)
+
+
+def _phase_congruency(x, scales=4, orientations=4, k=2.0, eps=torch.finfo(torch.float32).eps):
+    """x: [N, 1, H, W] float64 -> [N, 1, H, W]; piq's _phase_congruency (EPS is float32's there: the reference runs in float32)"""
+    n, _, h, w = x.shape
+    filters = fsim_filters(h, w, scales, orientations).unsqueeze(0)
+    imagefft = torch.fft.fft2(x)
+    filters_ifft = torch.fft.ifft2(filters).real * math.sqrt(h * w)
+    eo = torch.fft.ifft2(imagefft * filters).view(n, orientations, scales, h, w)
+    even, odd = eo.real, eo.imag
+    an = torch.sqrt(even ** 2 + odd ** 2)
+    em_n = (filters.view(1, orientations, scales, h, w)[:, :, :1] ** 2).sum(dim=[-2, -1], keepdim=True)
+    sum_e, sum_o = even.sum(dim=2, keepdim=True), odd.sum(dim=2, keepdim=True)
+    x_energy = torch.sqrt(sum_e ** 2 + sum_o ** 2) + eps
+    mean_e, mean_o = sum_e / x_energy, sum_o / x_energy
+    energy = (even * mean_e + odd * mean_o - torch.abs(even * mean_o - odd * mean_e)).sum(dim=2, keepdim=True)
+    abs_eo = an[:, :, :1].reshape(n, orientations, 1, 1, h * w)
+    median_e2n = torch.median(abs_eo ** 2, dim=-1, keepdim=True).values          # lower median, like torch
+    mean_e2n = -median_e2n / math.log(0.5)
+    noise_power = mean_e2n / em_n
+    fi = filters_ifft.view(1, orientations, scales, h, w)
+    sum_an2 = (fi ** 2).sum(dim=-3, keepdim=True).sum(dim=[-1, -2], keepdim=True)
+    est = torch.zeros(1, orientations, 1, h, w, dtype=x.dtype)
+    for s_ in range(scales - 1):
+        est = est + (fi[:, :, s_:s_ + 1] * fi[:, :, s_ + 1:]).sum(dim=-3, keepdim=True)
+    sum_ai_aj = est.sum(dim=[-1, -2], keepdim=True)
+    noise_energy2 = 2 * noise_power * sum_an2 + 4 * noise_power * sum_ai_aj
+    tau = torch.sqrt(noise_energy2 / 2)
+    t = (tau * math.sqrt(math.pi / 2) + k * torch.sqrt((2 - math.pi / 2) * tau ** 2)) / 1.7
+    energy = torch.max(energy - t, torch.zeros_like(t))
+    return ((energy.sum(dim=[1, 2]) + eps) / (an.sum(dim=[1, 2]) + eps)).unsqueeze(1)
+
+
+def _similarity(a, b, c):                                          # piq.functional.similarity_map
+    return (2.0 * a * b + c) / (a ** 2 + b ** 2 + c)
+
+
+def fsim(x, y):
+    """piq.fsim(x, y, reduction='none'-like: one value per sample), data_range 1, chromatic"""
+    x, y = x.double() * 255, y.double() * 255
+    f = metric_factor(x.shape[-2], x.shape[-1])
+    x, y = F.avg_pool2d(x, f), F.avg_pool2d(y, f)
+    m = torch.tensor([[0.299, 0.587, 0.114], [0.5959, -0.2746, -0.3213], [0.2115, -0.5227, 0.3112]], dtype=torch.float64)   # rgb2yiq
+    xq, yq = torch.einsum("kc,nchw->nkhw", m, x), torch.einsum("kc,nchw->nkhw", m, y)
+    xl, yl = xq[:, :1], yq[:, :1]
+    pc_x, pc_y = _phase_congruency(xl), _phase_congruency(yl)
+    sch = torch.tensor([[-3.0, 0.0, 3.0], [-10.0, 0.0, 10.0], [-3.0, 0.0, 3.0]], dtype=torch.float64) / 16
+    kern = torch.stack([sch, sch.t()]).unsqueeze(1)
+
+    def grad(z):
+        return torch.sqrt((F.conv2d(z, kern, padding=1) ** 2).sum(dim=1, keepdim=True))
+    pc = _similarity(pc_x, pc_y, 0.85)
+    gm = _similarity(grad(xl), grad(yl), 160.0)
+    pc_max = torch.where(pc_x > pc_y, pc_x, pc_y)
+    score = gm * pc * pc_max
+    s_i, s_q = _similarity(xq[:, 1:2], yq[:, 1:2], 200.0), _similarity(xq[:, 2:], yq[:, 2:], 200.0)
+    score = score * torch.abs(s_i * s_q) ** 0.03
+    return score.sum(dim=[1, 2, 3]) / pc_max.sum(dim=[1, 2, 3])

@@ -17,7 +17,7 @@ def test_cli_test_others(spec, capsys):
     from utils import cli
     table = cli.main(["test", "--config", os.path.join(CFG, "others.yaml"), "--model.func_spec", spec,
                       "--data.n_frames", "3", "--data.height", "64", "--data.width", "96", "--trainer.logger", "false"])
-    assert table.shape == (3, 3) and torch.isfinite(table).all()      # PSNR, SSIM, iCID per frame
+    assert table.shape == (3, 4) and torch.isfinite(table).all()      # PSNR, SSIM, FSIM, iCID per frame
     assert "Test PSNR" in capsys.readouterr().out
     # the transfer must improve on doing nothing for this synthetic distortion
     from utils.data import SyntheticStereoFrames
@@ -25,7 +25,7 @@ def test_cli_test_others(spec, capsys):
     fr = SyntheticStereoFrames(3, 64, 96)
     base = torch.stack([psnr(fr[i]["target"][None], fr[i]["gt"][None]) for i in range(3)]).mean()
     assert float(table[:, 0].mean()) > float(base)
-    assert 0 < float(table[:, 1].mean()) <= 1 and 0 <= float(table[:, 2].mean()) < 1
+    assert 0 < float(table[:, 1].mean()) <= 1 and 0 < float(table[:, 2].mean()) <= 1 and 0 <= float(table[:, 3].mean()) < 1
 
 
 def test_runner_numpy_path_equals_cuda_path():
@@ -45,7 +45,7 @@ def test_cli_dcmcs3di(capsys):
     from utils import cli
     table = cli.main(["test", "--config", os.path.join(CFG, "dcmcs3di.yaml"), "--model.extraction_layers", "2",
                       "--model.transfer_layers", "1", "--data.n_frames", "2", "--data.height", "32", "--data.width", "64"])
-    assert table.shape == (2, 3) and torch.isfinite(table).all()
+    assert table.shape == (2, 4) and torch.isfinite(table).all()
 
 
 def test_cli_dmsct_with_checkpoint(tmp_path, capsys):
@@ -62,7 +62,7 @@ def test_cli_dmsct_with_checkpoint(tmp_path, capsys):
     args = ["test", "--config", os.path.join(CFG, "dmsct.yaml"), "--ckpt_path", ckpt, "--data.n_frames", "2", "--data.height", "128",
             "--data.width", "192"]
     table = cli.main(args)
-    assert table.shape == (2, 3) and torch.isfinite(table).all()
+    assert table.shape == (2, 4) and torch.isfinite(table).all()
     assert "Test PSNR" in capsys.readouterr().out
     assert torch.equal(table, cli.main(args))                                     # deterministic, weights come from the file
     # the table is what the loaded model computes

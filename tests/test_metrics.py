@@ -42,6 +42,22 @@ def test_oracle_icid_vs_reference_run(golden_dir):
         assert float(om.icid(x, x)) == 0.0 == float(g[tag + "/icid_same"])
 
 
+def test_oracle_fsim_properties():
+    """piq.fsim restated (parity unpinned): structural properties of the restatement itself"""
+    gen = torch.Generator().manual_seed(2)
+    x = torch.rand(2, 3, 48, 64, generator=gen)
+    y = (x + 0.1 * torch.randn(2, 3, 48, 64, generator=gen)).clamp(0, 1)
+    assert torch.allclose(om.fsim(x, x), torch.ones(2, dtype=torch.float64), atol=1e-12)
+    a, b = om.fsim(x, y), om.fsim(y, x)
+    assert torch.allclose(a, b, atol=1e-12) and (a < 1).all() and (a > 0.5).all()               # symmetric, degraded
+    more = (x + 0.3 * torch.randn(2, 3, 48, 64, generator=gen)).clamp(0, 1)
+    assert (om.fsim(x, more) < a).all()                                                           # monotone in the noise level
+    f = om.fsim_filters(30, 45)
+    assert f.shape == (16, 30, 45) and float(f[:, 0, 0].abs().max()) == 0.0 and float(f.min()) >= 0.0
+    # the bank is symmetric under the half turn of the frequency plane for orientation 0 up to the angular spread: DC-free
+    assert float(f.sum()) > 0
+
+
 # ---- GPU ---------------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def hip():
@@ -101,6 +117,41 @@ def test_hip_icid_vs_oracle(hip, shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 40, 56), (1, 97, 131), (3, 270, 480), (1, 650, 700), (1, 1080, 1920), (2, 1083, 1925)])
+def test_hip_fsim_vs_oracle(hip, shape):
+    b, h, w = shape
+    x, y = _pair(2 * h + w, b, h, w)
+    got = hip.frame_fsim(x.cuda(), y.cuda()).cpu()
+    want = om.fsim(x, y)
+    print("\n[fsim %s] device %s oracle %s" % (shape, got.tolist(), want.tolist()))
+    assert got.shape == (b,) and torch.allclose(got, want, rtol=0, atol=2e-5), (got, want)
+    assert torch.allclose(hip.frame_fsim(x.cuda(), x.cuda()).cpu(), torch.ones(b, dtype=torch.float64), atol=1e-6)
+    assert torch.equal(got, hip.frame_fsim(x.cuda(), y.cuda()).cpu())          # deterministic
+    # batch composition does not matter (the median / thresholds are per image)
+    if b > 1:
+        assert torch.equal(got[1:2], hip.frame_fsim(x[1:2].cuda(), y[1:2].cuda()).cpu())
+
+
+@pytest.mark.gpu
+def test_hip_fsim_filter_bank_and_constants(hip):
+    """the device-built log-Gabor bank and noise constants against the oracle's (float64)"""
+    import ctypes
+    h, w = 131, 200
+    x = torch.rand(1, 3, h, w).cuda()
+    hip.frame_fsim(x, x)
+    filt, consts = hip._fsim_tables[(str(x.device), h, w)]
+    want = om.fsim_filters(h, w).reshape(16, -1)
+    assert float((filt.cpu().double() - want).abs().max()) < 1e-6
+    fi = torch.fft.ifft2(om.fsim_filters(h, w)).real * (h * w) ** 0.5
+    fi = fi.view(4, 4, h, w)
+    em = (om.fsim_filters(h, w).view(4, 4, h, w)[:, 0] ** 2).sum((1, 2))
+    an2 = (fi ** 2).sum((1, 2, 3))
+    aij = sum((fi[:, s] * fi[:, t]).sum((1, 2)) for s in range(3) for t in range(s + 1, 4))
+    got = consts.cpu()
+    assert torch.allclose(got[:, 0], em, rtol=1e-5) and torch.allclose(got[:, 1], an2, rtol=1e-4) and torch.allclose(got[:, 2], aij, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
 def test_runner_test_step_reports_all_metrics(hip):
     from methods import METRICS, Runner
     x, y = _pair(9, 2, 64, 96)
@@ -111,6 +162,7 @@ def test_runner_test_step_reports_all_metrics(hip):
     assert torch.allclose(m["Test PSNR"].cpu(), om.psnr(res, y), atol=1e-9)
     assert torch.allclose(m["Test SSIM"].cpu(), om.ssim(res, y), atol=2e-6)
     assert abs(float(m["Test iCID"][1]) - float(om.icid(res[1:2], y[1:2]))) < 5e-6
+    assert torch.allclose(m["Test FSIM"].cpu(), om.fsim(res, y), atol=2e-5)
     with pytest.raises(hip.CtHipError):
         hip.frame_ssim(torch.rand(1, 3, 8, 8).cuda(), torch.rand(1, 3, 8, 8).cuda())      # smaller than the 11x11 window
 
