@@ -114,6 +114,6 @@ def test_cli_on_the_artificial_grid(capsys):
     from utils import cli
     cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "color-transfer_amd", "configs", "others.yaml")
     table = cli.main(["test", "--config", cfg, "--data.synthetic", "artificial", "--data.n_frames", "1", "--data.height", "96", "--data.width", "128"])
-    assert table.shape == (31, 3) and torch.isfinite(table).all()
+    assert table.shape == (31, 4) and torch.isfinite(table).all()        # PSNR, SSIM, FSIM, iCID
     assert float(table[0, 0]) > float(table[1, 0]) - 50       # sanity: the identity sample is not worse than everything else
     assert "Test SSIM" in capsys.readouterr().out
