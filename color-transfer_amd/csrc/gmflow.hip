@@ -737,6 +737,104 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(const float *__res
 #endif
 }
 
+// -------------------------------------------------------------------------------------------------
+// K = 128, N <= 128 (the q / k / v / merge projections: 8 of the 10 linears of a transformer layer): the whole pre-split W
+// (4 chunks x 24 KiB = 96 KiB) stays RESIDENT in LDS for the lifetime of a persistent 8-wave workgroup, and the activations
+// never touch LDS: a lane of v_mfma_f32_32x32x16_bf16 holds 8 consecutive channels of ONE token, which is what it gets from
+// two 16-byte loads of a row-major [T][K] row.  Each wave walks 32-token tiles on its own (32 tokens x all 128 features:
+// no wave needs another wave's tokens, so there is no barrier after the prologue); per chunk a lane loads its token's 64
+// contiguous bytes (channels 16 hl .. 16 hl + 15: K step s of lane half hl is channels 16 hl + 8 s + j -- any bijection is
+// a valid contraction order as long as W is read with the same one, group 2 hl + s), the next chunk's / tile's loads are
+// in flight under the 48 MFMAs of the current chunk, and its split (VALU) is scheduled between them.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) void linear_split_wres_kernel(const float *__restrict__ x, const uint4 *__restrict__ wp,
+                                                                    const float *__restrict__ bias, float *__restrict__ out, long long T,
+                                                                    int N, int act, int n_tiles) {
+    constexpr int NC = 4;                          // K = 128
+    __shared__ uint4 Ws[NC * kLsW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, hl = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < NC * kLsW / 512; ++j) Ws[tid + 512 * j] = wp[tid + 512 * j];
+    const uint4 *wb = Ws + 2 * hl * 128 + nl;
+    float bb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bb[j] = (bias && 32 * j + nl < N) ? bias[32 * j + nl] : 0.f;
+    __syncthreads();
+
+    const int stride = gridDim.x * 8;
+    int tile = blockIdx.x * 8 + wave;
+    if (tile >= n_tiles) return;
+    auto row_ptr = [&](int t) {
+        const long long tr = (long long)t * 32 + nl;
+        return reinterpret_cast<const float4 *>(x + (tr < T ? tr : T - 1) * 128 + 16 * hl);
+    };
+    float4 raw[2][4];                              // raw X of the chunk after the current one (ring of two)
+    uint4 fa[2][2][3];                             // A fragments of the current / next chunk
+    auto fetch = [&](const float4 *p, int c, float4 (&r)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[q] = p[8 * c + q];
+    };
+    auto split_x = [&](const float4 (&px)[4], uint4 (&f)[2][3]) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float v[8] = {px[2 * s].x, px[2 * s].y, px[2 * s].z, px[2 * s].w, px[2 * s + 1].x, px[2 * s + 1].y, px[2 * s + 1].z, px[2 * s + 1].w};
+            split3x8g(v, f[s][0], f[s][1], f[s][2]);
+        }
+    };
+    const float4 *xp = row_ptr(tile);
+    fetch(xp, 0, raw[0]);
+    fetch(xp, 1, raw[1]);
+    split_x(raw[0], fa[0]);
+    for (; tile < n_tiles; tile += stride) {
+        const int next = tile + stride;
+        const float4 *xn = row_ptr(next < n_tiles ? next : tile);
+        f32x16g acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            // raw[(c + 1) & 1] holds chunk c+1 (of this tile, or chunk 0 of the next tile): split it under the MFMAs of chunk c;
+            // raw[c & 1] is free: fetch chunk c+2 into it
+            if (c + 2 < NC) fetch(xp, c + 2, raw[c & 1]);
+            else fetch(xn, c + 2 - NC, raw[c & 1]);
+            const uint4 *wc = wb + c * kLsW;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                uint4 b[4][3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) b[j][p] = wc[(4 * p + s) * 128 + 32 * j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mfma_split6(acc[j], fa[c & 1][s], b[j]);
+            }
+            split_x(raw[(c + 1) & 1], fa[(c + 1) & 1]);
+#pragma unroll
+            for (int q = 0; q < 24; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            }
+        }
+        // epilogue: lane = feature column, registers = token rows; 32 lanes store 128 contiguous bytes of a token
+        const long long t0 = (long long)tile * 32;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nf = 32 * j + nl;
+            if (nf < N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long t = t0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+                    const float v = acc[j][r] + bb[j];
+                    if (t < T) out[t * N + nf] = act == 6 ? gelu_as(v) : v;
+                }
+            }
+        }
+        xp = xn;
+    }
+}
+
 constexpr int kSsRow(int C) { return 2 * C + 16; }   // bytes per LDS row of a split tile: 16-byte fragment reads are conflict free
 
 template <int C, int CV, bool MAP, bool SS>
@@ -1551,6 +1649,17 @@ int ct_linear_tokens_split_f32(const float *x, const float *x2, int k1, const vo
     const int n_nt = (n + 127) / 128;
     // 64-token tiles while 128-token tiles would leave CUs without a workgroup (2 per CU are resident)
     const long long tiles128 = (tokens + 127) / 128 * n_nt;
+#ifndef CT_LS_NOWRES
+    if (k == 128 && n <= 128 && !x2) {              // q / k / v / merge projections: W resident in LDS, X straight into MFMA fragments
+        const long long tiles32 = (tokens + 31) / 32;
+        long long g = (tiles32 + 7) / 8;
+        if (g > 256) g = 256;
+        hipLaunchKernelGGL(ct::linear_split_wres_kernel, dim3((unsigned)g), dim3(512), 0, (hipStream_t)stream, x, (const uint4 *)wp, bias, out,
+                           tokens, n, act, (int)tiles32);
+        CT_CHECK_LAUNCH();
+        return CT_OK;
+    }
+#endif
     if (tiles128 >= 2 * 256) {
         hipLaunchKernelGGL(ct::linear_split_kernel<128>, dim3((unsigned)tiles128), dim3(256), 0, (hipStream_t)stream, x, x2, k1,
                            (const uint4 *)wp, bias, out, tokens, k, n, act, n_nt);
