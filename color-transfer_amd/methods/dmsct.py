@@ -88,8 +88,15 @@ class DMSCT(torch.nn.Module):
         _, _, height, width = reference.shape
         pad_size = self.derive_pad_size(reference.shape)
         pad = torch.nn.functional.pad
-        ft = self.encoder(pad(target, pad_size, mode="replicate"))
-        fr = self.encoder(pad(reference, pad_size, mode="replicate"))
+        if isinstance(self.encoder, smp_hip.EfficientNetEncoder):
+            # both views in one batch (inference: every layer, the SE gate included, is per sample -- same numbers as the
+            # reference's two calls, dmsct.py:98-99, half the launches)
+            n = target.shape[0]
+            both = self.encoder(torch.cat([pad(target, pad_size, mode="replicate"), pad(reference, pad_size, mode="replicate")], dim=0))
+            ft, fr = [f[:n] for f in both], [f[n:] for f in both]
+        else:
+            ft = self.encoder(pad(target, pad_size, mode="replicate"))
+            fr = self.encoder(pad(reference, pad_size, mode="replicate"))
         features = self.fuse_features(m["flow"], m["fwd_occ"], ft, fr, pad_size)
         return torch.clamp(target + self.head(self.decoder(*features))[:, :, :height, :width], min=0, max=1)
 

@@ -22,9 +22,10 @@ full = t_ms(lambda: m(a, b), n)
 match = t_ms(lambda: m.match(a, b), n)
 pad = m.derive_pad_size(a.shape)
 ap = torch.nn.functional.pad(a, pad, mode="replicate")
-enc = t_ms(lambda: m.encoder(ap), n)
+both = torch.cat([ap, ap], dim=0)
+enc = t_ms(lambda: m.encoder(both), n)                 # both views in one batch, as DMSCT.forward runs it
 feats = m.encoder(ap)
 fused = [torch.cat([f, f, f[:, :1]], 1).contiguous() for f in feats]
 dec = t_ms(lambda: m.head(m.decoder(*fused)), n)
-print("DMSCT %dx%d: forward %.2f ms (%.2f pairs/s) = matcher %.2f + encoder 2 x %.2f + decoder/head %.2f + fusion %.2f" % (
-    H, W, full, 1e3 / full, match, enc, dec, full - match - 2 * enc - dec))
+print("DMSCT %dx%d: forward %.2f ms (%.2f pairs/s) = matcher %.2f + encoder (both views, one batch) %.2f + decoder/head %.2f + fusion %.2f" % (
+    H, W, full, 1e3 / full, match, enc, dec, full - match - enc - dec))
