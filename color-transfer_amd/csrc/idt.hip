@@ -437,6 +437,24 @@ static int idt_grid(int64_t n, int batch) {
     return (int)want;
 }
 
+static int idt_minmax_grid(int64_t n, int batch) {
+    static const int per_call = [] { const char *e = getenv("CT_IDT_MINMAX_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+    int64_t want = (n / 4 + kIdtBlock - 1) / kIdtBlock;
+    int64_t cap = per_call / (batch > 0 ? batch : 1);
+    if (cap < 16) cap = 16;
+    if (want > cap) want = cap;
+    return want < 1 ? 1 : (int)want;
+}
+static int idt_apply_grid(int64_t n, int batch) {
+    static const int per_call = [] { const char *e = getenv("CT_IDT_APPLY_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : kTargetBlocks; }();
+    int64_t want = (n + kIdtBlock - 1) / kIdtBlock;
+    int64_t cap = per_call / (batch > 0 ? batch : 1);
+    if (cap > 1024) cap = 1024;          // its 6 same-address atomicMax per workgroup again: 1024 beat 2048 by 4 % (one pair per call)
+    if (cap < 8) cap = 8;
+    if (want > cap) want = cap;
+    return want < 1 ? 1 : (int)want;
+}
+
 template <typename T>
 static int idt_impl(const T *target, int64_t n_t, const T *reference, int64_t n_r, int batch, const double *rot,
                     const double *rinv, int n_iter, int bins, int round_dr_f32, double *out, void *ws, size_t ws_bytes,
@@ -452,20 +470,28 @@ static int idt_impl(const T *target, int64_t n_t, const T *reference, int64_t n_
     if (n_iter == 0) return CT_E_BADARG;   // the host returns the input untouched in that case
     if (n_t == 0) return CT_OK;
     if ((e = hipMemsetAsync(ws, 0, l.zero_bytes, s)) != hipSuccess) return (int)e;
-    const int gt = idt_grid(n_t, batch), gr = idt_grid(n_r, batch);
+    const int gt = idt_apply_grid(n_t, batch);
+    // the lo/hi sweeps end in 6 * rotations same-address 64-bit atomicMax per workgroup, which serialise in L2 (~20 ns each):
+    // with 2048 workgroups that tail was 40 of the sweep's 45 us -- one workgroup per CU keeps it under 5 us
+    const int gmm_t = idt_minmax_grid(n_t, batch), gmm_r = idt_minmax_grid(n_r, batch);
     // reference: lo/hi of every iteration's projection in one go; target: iteration 0 only
     if (n_r > 0) {
-        hipLaunchKernelGGL((idt_minmax_kernel<T, 8>), dim3(gr, batch), dim3(kIdtBlock), 0, s, reference, n_r, rot, n_iter, 0,
+        hipLaunchKernelGGL((idt_minmax_kernel<T, 8>), dim3(gmm_r, batch), dim3(kIdtBlock), 0, s, reference, n_r, rot, n_iter, 0,
                            n_iter, 1, l.mm);
         CT_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL((idt_minmax_kernel<T, 8>), dim3(gt, batch), dim3(kIdtBlock), 0, s, target, n_t, rot, n_iter, 0, 1, 0,
+    hipLaunchKernelGGL((idt_minmax_kernel<T, 8>), dim3(gmm_t, batch), dim3(kIdtBlock), 0, s, target, n_t, rot, n_iter, 0, 1, 0,
                        l.mm);
     CT_CHECK_LAUNCH();
     // the histogram flush is 6*bins global integer atomics per workgroup onto the SAME addresses: keep the grid at
     // ~2 workgroups per CU (contended same-address atomics are an order of magnitude slower, MI355X_MICROARCH.md)
     int gh = idt_grid((n_t > n_r ? n_t : n_r) / 4 + 1, batch);
-    { int cap = 1024 / batch; cap = cap > 512 ? 512 : (cap < 64 ? 64 : cap); if (gh > cap) gh = cap; }   // per pair
+    {
+        static const int hist_cap = [] { const char *e = getenv("CT_IDT_HIST_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+        int cap = 2 * hist_cap / batch;
+        cap = cap > hist_cap ? hist_cap : (cap < 64 ? 64 : cap);
+        if (gh > cap) gh = cap;                              // per pair
+    }
     for (int it = 0; it < n_iter; ++it) {
         unsigned short *bi = (dbg && dbg->binidx) ? dbg->binidx : nullptr;
         if (it == 0) {

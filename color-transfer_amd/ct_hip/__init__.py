@@ -11,6 +11,7 @@ GPU raises.
 import ctypes
 import os
 import threading
+import numpy as np
 
 import torch
 
@@ -141,6 +142,36 @@ def workspace(kind, n_pixels, n_images, device, need=None):
             buf = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
             _ws_cache[key] = buf
     return buf
+
+
+_upload_rings = {}                               # device index -> [pinned uint8 [slots, bytes], events, next slot]
+_UPLOAD_SLOTS, _UPLOAD_BYTES = 32, 1 << 14
+
+
+def _upload_small(arr, device):
+    """A small host array -> device tensor WITHOUT a blocking copy: staged through a ring of pinned slots and copied
+    asynchronously on the current stream (a pageable `.to(device)` is a synchronous hipMemcpy: it would drain the stream on
+    every call and serialise the host with the GPU)."""
+    arr = np.ascontiguousarray(arr)
+    if arr.nbytes > _UPLOAD_BYTES:
+        return torch.from_numpy(arr).to(device)
+    with _lock:
+        ring = _upload_rings.get(device.index)
+        if ring is None:
+            ring = [torch.empty((_UPLOAD_SLOTS, _UPLOAD_BYTES), dtype=torch.uint8).pin_memory(), [None] * _UPLOAD_SLOTS, 0]
+            _upload_rings[device.index] = ring
+        slot = ring[2]
+        ring[2] = (slot + 1) % _UPLOAD_SLOTS
+    if ring[1][slot] is not None:
+        ring[1][slot].synchronize()                # the copy that last used this slot (32 calls ago) has long finished
+    host = ring[0][slot, :arr.nbytes].view(torch.from_numpy(arr).dtype).view(arr.shape)
+    host.copy_(torch.from_numpy(arr))
+    dev = torch.empty(arr.shape, dtype=host.dtype, device=device)
+    dev.copy_(host, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    ring[1][slot] = ev
+    return dev
 
 
 def _as_batch(img):
@@ -453,7 +484,7 @@ def idt(target, reference, rotations, bins=255, round_dr_f32=None, out=None, deb
         rot = np.broadcast_to(rot, (B,) + rot.shape)
     n_iter = rot.shape[1]
     rinv = np.linalg.inv(rot)                       # host 3x3 inverses (the reference LU-solves, iterative.py:55)
-    both = torch.from_numpy(np.ascontiguousarray(np.stack([rot, rinv]).reshape(2, B, n_iter, 9))).to(x.device)
+    both = _upload_small(np.ascontiguousarray(np.stack([rot, rinv]).reshape(2, B, n_iter, 9)), x.device)
     if round_dr_f32 is None:
         round_dr_f32 = x.dtype == torch.float32
     if out is None:
