@@ -107,7 +107,7 @@ int ct_distort_u8(const uint8_t *in, int height, int width, int kind, double par
     if (kind == ct::kDistContrast) {
         if (hipMemsetAsync(ws, 0, 8, s) != hipSuccess) return (int)hipGetLastError();
         const int blocks = (int)((n + ct::kBlock * 8 - 1) / (ct::kBlock * 8));
-        hipLaunchKernelGGL(ct::gray_sum_kernel, dim3(blocks < 2048 ? blocks : 2048), dim3(ct::kBlock), 0, s, in, n, (unsigned long long *)ws);
+        hipLaunchKernelGGL(ct::gray_sum_kernel, dim3(blocks < 256 ? blocks : 256), dim3(ct::kBlock), 0, s, in, n, (unsigned long long *)ws);   // one same-address atomic per workgroup: keep them few
         CT_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(ct::distort_kernel, dim3((unsigned)((n + ct::kBlock - 1) / ct::kBlock)), dim3(ct::kBlock), 0, s, in, n, kind, (float)param,
