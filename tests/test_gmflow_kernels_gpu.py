@@ -121,7 +121,7 @@ def test_eltwise(hip):
 
 @pytest.mark.parametrize("mode", ["split", "exact"])
 @pytest.mark.parametrize("t,k,n,act", [(200, 128, 128, 0), (1000, 256, 1024, 6), (77, 1024, 128, 0), (33, 128, 128, 0), (300, 160, 200, 6),
-                                       (129, 32, 2, 0), (4000, 128, 384, 0)])
+                                       (129, 32, 2, 0), (4000, 128, 384, 0), (1000, 128, 96, 6), (70000, 128, 128, 0), (31, 128, 3, 0)])
 def test_linear_tokens(hip, t, k, n, act, mode):
     """both arithmetic paths of nn.Linear on tokens (float32 MFMA / three-piece bf16 split, six MFMAs per product) against
     float64 torch -- the split path is held to the same float32-rounding-level bound"""
