@@ -854,7 +854,12 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
     // one is multiplied), staged in LDS, and read from there as MFMA operands.
     constexpr int SROW = kSsRow(C);                 // SS: K tile as [piece][key][C] bf16, rows padded to SROW bytes
     __shared__ __attribute__((aligned(16))) float Ks[SS ? 3 * 32 * SROW / 4 : 32 * KLD];
-    __shared__ float Vs[32 * VLD];
+    // SS with an MFMA value path: V as [piece][key][CV] bf16 too, rows of VROWB bytes with (VROWB / 4) % 64 == 16 or 48, so the
+    // four rows a transposed read gathers lie in four disjoint 16-bank windows (cdna_hip_programming.md T10)
+    constexpr bool PVS = SS && CV >= 32;
+    constexpr int VROWB = (CV * 2) % 256 == 0 ? CV * 2 + 64 : CV * 2;
+    static_assert(!PVS || ((VROWB / 4) % 64 == 16 || (VROWB / 4) % 64 == 48), "V image rows must not share banks");
+    __shared__ __attribute__((aligned(16))) float Vs[PVS ? 3 * 32 * VROWB / 4 : 32 * VLD];
     __shared__ int Rs[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, hl = lane >> 5;
     const int b = blockIdx.y;
@@ -952,7 +957,19 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
                 *reinterpret_cast<float4 *>(Ks + key * KLD + 4 * c4) = kpre[i];
             }
         }
-        if constexpr (CV >= 32) {
+        if constexpr (PVS) {
+#pragma unroll
+            for (int i = 0; i < VV4; ++i) {
+                const int f = tid + i * 256, key = f / (CV / 4), c4 = f - key * (CV / 4);
+                unsigned int h0, m0, l0, h1, m1, l1;
+                split3x2g(vpre[i].x, vpre[i].y, h0, m0, l0);
+                split3x2g(vpre[i].z, vpre[i].w, h1, m1, l1);
+                unsigned char *vd = reinterpret_cast<unsigned char *>(Vs) + key * VROWB + 8 * c4;
+                *reinterpret_cast<uint2 *>(vd) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2 *>(vd + 32 * VROWB) = make_uint2(m0, m1);
+                *reinterpret_cast<uint2 *>(vd + 64 * VROWB) = make_uint2(l0, l1);
+            }
+        } else if constexpr (CV >= 32) {
 #pragma unroll
             for (int i = 0; i < VV4; ++i) {
                 const int f = tid + i * 256, key = f / (CV / 4), c4 = f - key * (CV / 4);
@@ -1053,7 +1070,41 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
         psum += __shfl_xor(psum, 32, 64);
         l_run = l_run * corr + psum;
         m_run = m_new;
-        if constexpr (CV >= 32) {
+        if constexpr (PVS) {
+#pragma unroll
+            for (int j = 0; j < NVT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[j][r] *= corr;
+            // O^T[c][query] += sum_key V[key][c] P[key][query] on the bf16 pipe (three pieces each, six MFMAs per product).
+            // B = P: the score tile already has its column (query) on the lane and its rows (keys) in the registers, so the
+            // registers 8t .. 8t+7 of a lane ARE its B fragment of K step t (keys 16t + 8(j>>2) + 4hl + (j&3), j = 0..7) --
+            // no lane movement.  A = V^T: the same 8 keys of channel nl, i.e. two 4-key column gathers from the row-major
+            // [key][channel] image: ds_read_b64_tr_b16 (lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3, and
+            // receives its own column of the four rows).
+            typedef short s16x4g __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) s16x4g *lds_s16x4;
+            const unsigned char *vb = reinterpret_cast<const unsigned char *>(Vs) + (4 * hl + ((lane & 15) >> 2)) * VROWB +
+                                      (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float x[8] = {s[8 * t], s[8 * t + 1], s[8 * t + 2], s[8 * t + 3], s[8 * t + 4], s[8 * t + 5], s[8 * t + 6], s[8 * t + 7]};
+                uint4 pf[3];
+                split3x8g(x, pf[0], pf[1], pf[2]);
+#pragma unroll
+                for (int j = 0; j < NVT; ++j) {
+                    uint4 vf[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        const unsigned char *a = vb + (p * 32 + 16 * t) * VROWB + 64 * j;
+                        const s16x4g lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a));
+                        const s16x4g hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a + 8 * VROWB));
+                        const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                        vf[p] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+                    }
+                    mfma_split6(o[j], vf, pf);
+                }
+            }
+        } else if constexpr (CV >= 32) {
 #pragma unroll
             for (int j = 0; j < NVT; ++j)
 #pragma unroll
@@ -1714,7 +1765,7 @@ int ct_attention_tokens_f32(const float *q, const float *k, const float *v, cons
     if (batch == 0) return CT_OK;
     dim3 grid((len + 127) / 128, batch, nsplit);
     float *nostats = nullptr;
-#define CT_ATT(CVV, MAPPED) hipLaunchKernelGGL((ct::attention_tokens_kernel<128, CVV, MAPPED, false>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, region, rowmap, out, nostats, len, scale, ws)
+#define CT_ATT(CVV, MAPPED) hipLaunchKernelGGL((ct::attention_tokens_kernel<128, CVV, MAPPED, true>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, region, rowmap, out, nostats, len, scale, ws)
     if (cv == 128) { if (rowmap) CT_ATT(128, true); else CT_ATT(128, false); }
     else { if (rowmap) CT_ATT(2, true); else CT_ATT(2, false); }
 #undef CT_ATT
