@@ -32,6 +32,7 @@ constexpr int kFsMaxPlans = 16;
 static FsimPlan g_plans[kFsMaxPlans];
 static int g_n_plans = 0;
 static std::mutex g_plan_mutex;
+static std::mutex g_exec_mutex;     // a cached hipFFT plan carries its stream and work area: set + execute sequences are serialised
 
 // plans for `batch` luminance images (forward) and batch * 16 filtered spectra (inverse); work area supplied per call.
 // Returns a COPY of the cache entry (handles are plain values; the table may be reshuffled by the next call).
@@ -381,6 +382,7 @@ int ct_fsim_setup_f32(int h, int w, float *filters, double *consts, void *ws, si
     const ct::FsimLayout l = ct::fsim_layout(ws, 2, P, pl->work);
     if (ws_bytes < l.total) return CT_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> exec_lock(ct::g_exec_mutex);
     hipLaunchKernelGGL(ct::fsim_filters_kernel, dim3((P + 255) / 256), dim3(256), 0, s, filters, hp, wp);
     CT_CHECK_LAUNCH();
     const size_t n = (size_t)ct::kFsK * P;
@@ -408,6 +410,7 @@ int ct_frame_fsim_f32(const float *a, const float *b, double *out, int batch, in
     hipStream_t s = (hipStream_t)stream;
     const dim3 gp((P + 255) / 256, imgs);
     const float invP = 1.0f / (float)P;
+    std::lock_guard<std::mutex> exec_lock(ct::g_exec_mutex);
     if (hipMemsetAsync(l.hist, 0, (size_t)imgs * ct::kFsO * 2048 * sizeof(unsigned int), s) != hipSuccess) return (int)hipGetLastError();
     hipLaunchKernelGGL(ct::fsim_prep_kernel, gp, dim3(256), 0, s, a, b, h, w, f, hp, wp, l.lum, l.iq);
     CT_CHECK_LAUNCH();
