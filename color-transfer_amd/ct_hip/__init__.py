@@ -987,6 +987,26 @@ def fb_check(fwd, bwd, alpha=0.01, beta=0.5):
     return fo, bo
 
 
+def nchw_to_tokens(x):
+    """[B,C,H,W] -> channels-last tokens [B, H*W, C] (transformer.py:238-239's flatten + permute) through the LDS-tiled transpose"""
+    _f32c(x)
+    b, c, h, w = x.shape
+    out = torch.empty((b, h * w, c), dtype=torch.float32, device=x.device)
+    check(lib().ct_nchw_to_rows_f32(_ptr(x), _ptr(out), b, c, h, w, c * h * w, c, 0, _stream()))
+    return out
+
+
+def tokens_to_nchw(t, h, w):
+    """tokens [B, H*W, C] -> [B,C,H,W]"""
+    _f32c(t)
+    b, l, c = t.shape
+    if l != h * w:
+        raise CtHipError("tokens_to_nchw: %d tokens are not %d x %d" % (l, h, w))
+    out = torch.empty((b, c, h, w), dtype=torch.float32, device=t.device)
+    check(lib().ct_rows_to_nchw_f32(_ptr(t), _ptr(out), b, c, h, w, c * h * w, c, 0, _stream()))
+    return out
+
+
 def pam_streaming(q, k, v, rgb, q_other, k_other):
     """DCMCS3DI's parallax attention through the streaming kernels (any width):
     q,k [B,64,H,W] = Q(left), K(right); v [B,64,H,W], rgb [B,3,H,W]; q_other,k_other = Q(right), K(left).

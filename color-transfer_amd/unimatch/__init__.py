@@ -152,11 +152,11 @@ def _lin(m, x, act=ACT_NONE, x2=None):
 
 
 def _tokens(x):                                        # [B,C,H,W] -> [B,H*W,C]  (transformer.py:238-239)
-    return x.flatten(2).transpose(1, 2).contiguous()
+    return ct_hip.nchw_to_tokens(x.contiguous())
 
 
 def _nchw(t, h, w):                                    # [B,H*W,C] -> [B,C,H,W]
-    return t.transpose(1, 2).reshape(t.shape[0], t.shape[2], h, w).contiguous()
+    return ct_hip.tokens_to_nchw(t.contiguous(), h, w)
 
 
 # ---- host-side tables (float32 arithmetic identical to the reference's torch code) ---------------------------------
