@@ -844,7 +844,10 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 1) void attention_tokens_kernel(
                                                                const float *__restrict__ v, const int *__restrict__ region,
                                                                const int *__restrict__ rowmap, float *__restrict__ out,
                                                                float *__restrict__ stats, int L, float scale,
-                                                               float *__restrict__ part) {
+                                                               float *__restrict__ part, long long kv_shift = 0, long long kv_total = 0) {
+    // kv_shift (rowmap launches only): the keys / values of token (b, i) live kv_shift rows further (mod kv_total) than its
+    // query -- the cross attention of transformer.py:281-287 attends every image to the OTHER half of the batch, which the
+    // reference materialises as torch.cat(chunk(2)[::-1]) after every layer
     constexpr int CH = C / 2;                       // channels per lane half
     constexpr int NVT = CV >= 32 ? CV / 32 : 1;     // 32-channel value tiles on the MFMA path
     constexpr int KLD = C + 4;                      // padded LDS rows: the 16-lane column reads (b128) are conflict free
@@ -875,6 +878,14 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 1) void attention_tokens_kernel(
     auto row = [&](int i) -> size_t {
         if constexpr (MAP) return (size_t)rowmap[tb + i];
         else return tb + i;
+    };
+    auto kvrow = [&](int i) -> size_t {
+        size_t r = row(i);
+        if constexpr (MAP) {
+            r += (size_t)kv_shift;
+            if (r >= (size_t)kv_total && kv_total > 0) r -= (size_t)kv_total;
+        }
+        return r;
     };
     // B operand of S^T = K Q^T : lane (query nl, half hl) holds q[query][hl*C/2 + p], p < C/2
     float qb[SS ? 1 : CH];
@@ -907,13 +918,13 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 1) void attention_tokens_kernel(
 #pragma unroll
         for (int i = 0; i < KV4; ++i) {
             const int key = (tid + i * 256) / (C / 4);
-            krow[i] = row(j0 + key < L ? j0 + key : L - 1);
+            krow[i] = kvrow(j0 + key < L ? j0 + key : L - 1);
         }
         if constexpr (CV >= 32) {
 #pragma unroll
             for (int i = 0; i < VV4; ++i) {
                 const int key = (tid + i * 256) / (CV / 4);
-                vrow[i] = row(j0 + key < L ? j0 + key : L - 1);
+                vrow[i] = kvrow(j0 + key < L ? j0 + key : L - 1);
             }
         }
     };
@@ -934,8 +945,8 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 1) void attention_tokens_kernel(
                 const int key = 2 * tid;
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
                 if constexpr (MAP) {
-                    if (j0 + key < L) { const float2 u = *reinterpret_cast<const float2 *>(v + row(j0 + key) * 2); t.x = u.x; t.y = u.y; }
-                    if (j0 + key + 1 < L) { const float2 u = *reinterpret_cast<const float2 *>(v + row(j0 + key + 1) * 2); t.z = u.x; t.w = u.y; }
+                    if (j0 + key < L) { const float2 u = *reinterpret_cast<const float2 *>(v + kvrow(j0 + key) * 2); t.x = u.x; t.y = u.y; }
+                    if (j0 + key + 1 < L) { const float2 u = *reinterpret_cast<const float2 *>(v + kvrow(j0 + key + 1) * 2); t.z = u.x; t.w = u.y; }
                 } else if (j0 + key + 1 < L) t = *reinterpret_cast<const float4 *>(v + (tb + j0 + key) * 2);
                 else if (j0 + key < L) { const float2 u = *reinterpret_cast<const float2 *>(v + (tb + j0 + key) * 2); t.x = u.x; t.y = u.y; }
                 vpre[0] = t;
@@ -1760,14 +1771,17 @@ size_t ct_attention_workspace_bytes(int batch, int len, int cv, int nsplit) {
 }
 
 int ct_attention_tokens_f32(const float *q, const float *k, const float *v, const int *region, const int *rowmap, float *out,
-                            int batch, int len, int cv, float scale, int nsplit, float *ws, size_t ws_bytes, void *stream) {
+                            int batch, int len, int cv, float scale, int nsplit, float *ws, size_t ws_bytes, long long kv_shift,
+                            void *stream) {
     if (!q || !k || !v || !out || batch < 0 || len < 1 || (cv != 2 && cv != 128) || nsplit < 1 || nsplit > 64) return CT_E_BADARG;
+    const long long kv_total = (long long)batch * len;
+    if (kv_shift < 0 || kv_shift >= (kv_total > 0 ? kv_total : 1) || (kv_shift != 0 && !rowmap)) return CT_E_BADARG;
     if (nsplit > 1 && (!ws || ws_bytes < ct_attention_workspace_bytes(batch, len, cv, nsplit))) return CT_E_WORKSPACE;
     if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(out)) & 15) return CT_E_ALIGN;
     if (batch == 0) return CT_OK;
     dim3 grid((len + 127) / 128, batch, nsplit);
     float *nostats = nullptr;
-#define CT_ATT(CVV, MAPPED) hipLaunchKernelGGL((ct::attention_tokens_kernel<128, CVV, MAPPED, true>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, region, rowmap, out, nostats, len, scale, ws)
+#define CT_ATT(CVV, MAPPED) hipLaunchKernelGGL((ct::attention_tokens_kernel<128, CVV, MAPPED, true>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, region, rowmap, out, nostats, len, scale, ws, kv_shift, kv_total)
     if (cv == 128) { if (rowmap) CT_ATT(128, true); else CT_ATT(128, false); }
     else { if (rowmap) CT_ATT(2, true); else CT_ATT(2, false); }
 #undef CT_ATT

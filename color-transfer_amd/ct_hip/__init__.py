@@ -678,7 +678,7 @@ SIGNATURES.update({
     "ct_layernorm128_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_p]),
     "ct_attention_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int, _c_int, _c_int]),
     "ct_attention_tokens_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_int, _c_p,
-                                         ctypes.c_size_t, _c_p]),
+                                         ctypes.c_size_t, ctypes.c_longlong, _c_p]),
     "ct_nchw_to_rows_f32": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_ll, _c_int, _c_int, _c_p]),
     "ct_rows_to_nchw_f32": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_ll, _c_int, _c_int, _c_p]),
     "ct_attention_rows64_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_f, _c_p]),
@@ -896,10 +896,11 @@ def layernorm128(x, gamma, beta, residual=None):
     return out
 
 
-def attention_tokens(q, k, v, region=None, scale=None, rowmap=None, nsplit=None):
+def attention_tokens(q, k, v, region=None, scale=None, rowmap=None, nsplit=None, kv_shift=0):
     """q,k [B,L,128], v [B,L,128] or [B,L,2]; region int32 [B,L] or None -> [B,L,cv].
     With rowmap (int32 [B', L']): B' x L' attention problems whose token (b, i) is row rowmap[b, i] of the flattened
-    q / k / v / out -- window partitions without copies; the result has v's shape."""
+    q / k / v / out -- window partitions without copies; the result has v's shape.  kv_shift (with rowmap): keys / values are
+    read kv_shift rows further (mod the row count) than the queries: cross attention to the other half of the batch."""
     _f32c(q, k, v)
     c, cv = q.shape[-1], v.shape[-1]
     for t in (region, rowmap):
@@ -924,7 +925,7 @@ def attention_tokens(q, k, v, region=None, scale=None, rowmap=None, nsplit=None)
         need = lib().ct_attention_workspace_bytes(b, l, cv, nsplit)
         ws = workspace(-2, 0, 0, q.device, need=need)
     check(lib().ct_attention_tokens_f32(_ptr(q), _ptr(k), _ptr(v), _opt(region), _opt(rowmap), _ptr(out), b, l, cv,
-                                        float(scale if scale is not None else c ** -0.5), nsplit, _opt(ws), need, _stream()))
+                                        float(scale if scale is not None else c ** -0.5), nsplit, _opt(ws), need, int(kv_shift), _stream()))
     return out
 
 

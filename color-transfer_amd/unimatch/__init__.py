@@ -12,6 +12,8 @@ The stereo / depth branches of UniMatch are dead code for this repository and ar
 import math
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -253,17 +255,19 @@ class GMFlow(nn.Module):
 
     # ---- unimatch/attention.py:48-107 on tokens ----
     @staticmethod
-    def _window_attention(q, k, v, splits, shift, h, w):
+    def _window_attention(q, k, v, splits, shift, h, w, kv_swap=False):
         """split_feature / roll / merge_splits (attention.py:60-67,78-92,100-107) are one cached index table: the
         kernel gathers the tokens of a window and scatters its result through it, nothing is copied"""
         b = q.shape[0]
         rowmap = _window_rowmap(b, h, w, splits, shift, q.device)
         region = _region_ids(h, w, splits, q.device).repeat(b, 1).contiguous() if shift else None
-        return ct_hip.attention_tokens(q, k, v, region, rowmap=rowmap)
+        return ct_hip.attention_tokens(q, k, v, region, rowmap=rowmap, kv_shift=(q.shape[0] * q.shape[1]) // 2 if kv_swap else 0)
 
-    def _tlayer(self, m, source, target, h, w, shift, splits):          # transformer.py:45-147
+    def _tlayer(self, m, source, target, h, w, shift, splits, kv_swap=False):   # transformer.py:45-147
+        """kv_swap: the layer's target is `target` with the two halves of the batch exchanged (the reference's concat1): the
+        projections are per token, so they run on `target` as it is and the attention reads the keys / values of the other half"""
         q, k, v = _lin(m.q_proj, source), _lin(m.k_proj, target), _lin(m.v_proj, target)
-        msg = _lin(m.merge, self._window_attention(q, k, v, splits, shift, h, w))
+        msg = _lin(m.merge, self._window_attention(q, k, v, splits, shift, h, w, kv_swap))
         g1, b1 = m.norm1.weight.detach(), m.norm1.bias.detach()
         if m.no_ffn:
             return ct_hip.layernorm128(msg, g1, b1, residual=source)
@@ -272,12 +276,14 @@ class GMFlow(nn.Module):
         return ct_hip.layernorm128(x, m.norm2.weight.detach(), m.norm2.bias.detach(), residual=source)
 
     def _transformer(self, t0, t1, h, w, splits):                        # transformer.py:229-297
-        c0, c1 = torch.cat((t0, t1), dim=0), torch.cat((t1, t0), dim=0)
+        # concat1 of the reference (transformer.py:281-287) = concat0 with the batch halves exchanged, re-built after every layer:
+        # never materialised here -- the cross attention reads the other half's keys / values of the layer's input
+        c0 = torch.cat((t0, t1), dim=0)
         for i, layer in enumerate(self.transformer.layers):
             shift = i % 2 == 1
+            c_in = c0
             c0 = self._tlayer(layer.self_attn, c0, c0, h, w, shift, splits)
-            c0 = self._tlayer(layer.cross_attn_ffn, c0, c1, h, w, shift, splits)
-            c1 = torch.cat(c0.chunk(2, dim=0)[::-1], dim=0).contiguous()
+            c0 = self._tlayer(layer.cross_attn_ffn, c0, c_in, h, w, shift, splits, kv_swap=True)
         a, b_ = c0.chunk(2, dim=0)
         return a.contiguous(), b_.contiguous()
 

@@ -299,11 +299,14 @@ int ct_layernorm128_f32(const float *x, const float *gamma, const float *beta, c
  *   (shifted) window partition of attention.py:60-92,100-107 as a gather/scatter table instead of roll + permute.
  *   nsplit > 1: the keys are split over nsplit workgroups per query tile and merged by a second kernel (same result up
  *   to float rounding); ws needs ct_attention_workspace_bytes(batch, len, cv, nsplit).  Use it when batch*len/128
- *   workgroups cannot fill the 256 CUs.                                                                            */
+ *   workgroups cannot fill the 256 CUs.
+ *   kv_shift (rowmap launches; else 0): the keys / values of a token are read kv_shift rows further (mod batch*len) than
+ *   its query -- the cross attention of transformer.py:281-287 attends every image to the other half of the batch
+ *   (kv_shift = batch*len/2) without materialising torch.cat(chunk(2)[::-1]).                                       */
 size_t ct_attention_workspace_bytes(int batch, int len, int cv, int nsplit);
 int ct_attention_tokens_f32(const float *q, const float *k, const float *v, const int *region, const int *rowmap,
                             float *out, int batch, int len, int cv, float scale, int nsplit, float *ws,
-                            size_t ws_bytes, void *stream);
+                            size_t ws_bytes, long long kv_shift, void *stream);
 /* Streaming parallax attention on 64-channel row tokens (pasmnet/attention.py:39-46, utils.py:30-35,123-125), for
  * image widths whose score tile does not fit LDS (ct_pam_* need w <= 1982) and as the faster path in general:
  *   ct_attention_rows64_f32 : out[b][i][0:96] = softmax_j(q_i.k_j*scale) v[b][j][0:96]   (v != NULL), and/or the row

@@ -155,6 +155,22 @@ def test_linear_tokens_split_wide_dynamic_range(hip):
     assert ((out - ref).abs() / bound).max().item() < 4e-7
 
 
+def test_attention_kv_shift_is_the_swapped_concat(hip):
+    """cross attention against the other half of the batch (transformer.py:281-287's concat1) without the copy: reading keys /
+    values half the rows further == attending to torch.cat(chunk(2)[::-1]) -- bit for bit (same arithmetic, same order)"""
+    b, l = 4, 224
+    q, k, v = rnd(b, l, 128), rnd(b, l, 128), rnd(b, l, 128)
+    perm = torch.stack([torch.randperm(l, generator=G) + i * l for i in range(b)])          # a window-style row table
+    rowmap = perm.to(torch.int32).cuda()
+    region = torch.randint(0, 3, (b, l), generator=G, dtype=torch.int32).cuda()
+    swap = lambda t: torch.cat(t.chunk(2, dim=0)[::-1], dim=0).contiguous()
+    want = hip.attention_tokens(q.cuda(), swap(k).cuda(), swap(v).cuda(), region, rowmap=rowmap)
+    got = hip.attention_tokens(q.cuda(), k.cuda(), v.cuda(), region, rowmap=rowmap, kv_shift=b * l // 2)
+    assert torch.equal(got, want)
+    with pytest.raises(hip.CtHipError):
+        hip.attention_tokens(q.cuda(), k.cuda(), v.cuda(), kv_shift=5)                        # only with a row table
+
+
 def test_layernorm(hip):
     x, g, b, r = rnd(3, 50, 128) * 2 + 0.5, rnd(128), rnd(128), rnd(3, 50, 128)
     ref = F.layer_norm(x.double(), (128,), g.double(), b.double())
