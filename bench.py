@@ -204,6 +204,8 @@ def main():
                     " + ground-truth read of the fused per-frame PSNR" if (dom == k_apply and apply_planes == 3) else
                     ("" if dom == k_apply else " (statistics sweep: target + reference read)")),
                 "avg_launch_s": kern[dom]["t"],
+                # the same launch priced on the transfer's two planes only (as if the ground-truth read of the fused PSNR were free)
+                "frac_transfer_planes_only": 2 * B * PLANE_F32 / kern[dom]["t"] / HBM_PEAK,
                 "lab_arithmetic": ct_hip.lab_mode(),
                 "kernels": {k: {"GB/s": v["bytes"] / v["t"] / 1e9, "avg_launch_us": v["t"] * 1e6,
                                 "algorithmic_bytes_per_launch": v["bytes"]} for k, v in kern.items()},
