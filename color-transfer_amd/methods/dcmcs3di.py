@@ -11,32 +11,7 @@ import torch
 
 import ct_hip
 from pasmnet.attention import PAB
-from pasmnet.backbone import ResB
-
-
-def _packed_conv(conv):
-    """Packed (MFMA operand layout) copy of a conv's weights, cached ON the module and rebuilt when its parameters
-    change (in-place update -> _version, load_state_dict / .to() -> data_ptr).  A global cache keyed by id() would
-    hand a new module the packed weights of a dead one whose id and storage were recycled."""
-    ver = (conv.weight._version, conv.weight.data_ptr(), -1 if conv.bias is None else conv.bias._version,
-           -1 if conv.bias is None else conv.bias.data_ptr(), str(conv.weight.device))
-    hit = getattr(conv, "_ct_packed", None)
-    if hit is None or hit[0] != ver:
-        hit = (ver, ct_hip.pack_conv_weight(conv.weight, conv.bias))
-        conv._ct_packed = hit
-    return hit[1]
-
-
-def conv_forward(conv, x, act=0, residual=None, clamp=False, out=None):
-    wp, b = _packed_conv(conv)
-    return ct_hip.conv2d(x, wp, b, conv.out_channels, conv.kernel_size[0], act=act, residual=residual, clamp=clamp,
-                         out=out)
-
-
-def resb_forward(resb, x, out=None):
-    """x + conv(LeakyReLU(conv(x)))  (pasmnet/backbone.py:14-15)"""
-    t = conv_forward(resb.body[0], x, act=1)
-    return conv_forward(resb.body[2], t, residual=x, out=out)
+from pasmnet.backbone import ResB, conv_forward, resb_forward
 
 
 def sequential_forward(seq, x):
