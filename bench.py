@@ -37,6 +37,10 @@ N_PIX = H * W
 PLANE_F32 = N_PIX * 3 * 4                    # 24 883 200 B
 ALGO_BYTES_PER_PAIR = 3 * PLANE_F32          # read target, read reference, write output
 HBM_PEAK = 8.0e12                            # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
+BASELINE_METRIC = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+# arithmetic the headline path computes in, per Lab mode (ct_set_lab_mode)
+DTYPE = {"table": "f32 statistics / f64-grade apply (float32 I/O)",
+         "exact": "f64 (float32 I/O, float64 arithmetic)"}
 
 
 def synth_frames(frame_ids, device):
@@ -76,6 +80,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--pairs", type=int, default=16, help="stereopairs per step per GPU (one launch pair sweeps them all: the ~8 us a launch costs before it streams is paid once per step)")
     ap.add_argument("--metrics", default="psnr", help="per-frame metrics inside the timed region: psnr[,ssim,fsim,icid] or none")
+    ap.add_argument("--init-seconds", type=float, default=0.25, help="clock / code-object initialisation before the warm-up steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
@@ -107,10 +112,11 @@ def main():
     out = torch.empty_like(tgt)
     gt_nchw = gt.permute(0, 3, 1, 2).contiguous() if any(m in names for m in ("ssim", "fsim", "icid")) else None
     n_m = max(len(names), 1)
-    metrics = torch.zeros((K, B, n_m), dtype=torch.float64, device=device)      # this rank's [frames, n_metrics] table
-    gathered = torch.empty((world,) + tuple(metrics.shape), dtype=torch.float64, device=device) if world > 1 else None
-
+    # this rank's [frames, n_metrics] table.  PSNR-only (default): ct_reinhard_psnr_f32 writes its (mse, PSNR) records straight
+    # into the table -- no torch op at all inside the timed region besides the gather
     psnr_rec = torch.zeros((K, B, 2), dtype=torch.float64, device=device) if names == ["psnr"] else None
+    metrics = psnr_rec if psnr_rec is not None else torch.zeros((K, B, n_m), dtype=torch.float64, device=device)
+    gathered = torch.empty((world,) + tuple(metrics.shape), dtype=torch.float64, device=device) if world > 1 else None
 
     def step(i):
         if psnr_rec is not None:                    # transfer + per-frame PSNR in one fused call (ct_reinhard_psnr_f32)
@@ -129,16 +135,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # initialisation, not warm-up: every op of the timed region runs once (code objects load on first launch -- round 2's
+    # driver line paid 42 ms for the first launch of a torch copy kernel inside its 50 ms timed region) and the GPU is
+    # brought to its sustained clock with INIT_S seconds of the same step; the W warm-up steps follow as the contract says
+    step(0)
+    if world > 1:
+        dist.all_gather_into_tensor(gathered, metrics)      # warms the communicator
+    barrier()
+    t_init = time.perf_counter()
+    while time.perf_counter() - t_init < args.init_seconds:
+        for _ in range(8):
+            step(0)
+        torch.cuda.synchronize()
     for i in range(Wm):
-        step(0)
-    if world > 1:                                   # warm the communicator outside the timed region
-        dist.all_gather_into_tensor(gathered, metrics)
+        step(i % K)
     barrier()
     t0 = time.perf_counter()
     for i in range(K):
         step(i)
-    if psnr_rec is not None:
-        metrics[:, :, 0] = psnr_rec[:, :, 1]               # the [frames, n_metrics] table of this rank
     if world > 1:
         dist.all_gather_into_tensor(gathered, metrics)      # the per-frame metric gather (RCCL over xGMI)
     barrier()
@@ -181,39 +195,45 @@ def main():
         # algorithmic bytes per launch: the statistics sweep reads the 2B images once; the apply sweep reads B targets and
         # writes B results, and -- when the per-frame PSNR rides on it (table mode) -- also reads the B ground-truth frames
         # (the metric's one compulsory plane; the result it compares is still in registers)
-        apply_planes = 3 if (fused_psnr and table) else 2
-        kern = {k_stats: {"bytes": 2 * B * PLANE_F32, "t": t_stats},
-                k_apply: {"bytes": apply_planes * B * PLANE_F32, "t": t_apply}}
+        # algorithmic bytes per launch on SURVEY 8(d)'s planes: the statistics sweep reads the 2B images once; the apply sweep
+        # reads B targets and writes B results.  When the per-frame PSNR rides on the apply sweep (table mode) the launch also
+        # reads the B ground-truth frames: real traffic, but the metric's plane, not the transfer's -- reported as a
+        # secondary figure (`frac_with_metric_plane`), never as `frac`.
+        metric_planes = 1 if (fused_psnr and table) else 0
+        kern = {k_stats: {"bytes": 2 * B * PLANE_F32, "t": t_stats, "extra": 0},
+                k_apply: {"bytes": 2 * B * PLANE_F32, "t": t_apply, "extra": metric_planes * B * PLANE_F32}}
         dom = max(kern, key=lambda k: kern[k]["t"])
         ach = kern[dom]["bytes"] / kern[dom]["t"]
         # HBM traffic per launch of the dominant kernel from the committed PMC profile (separate --pmc passes,
         # FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md "HBM"), valid for the same pairs-per-step only
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             if tj.get("pairs_per_step") == B and tj.get("lab_mode") == ct_hip.lab_mode():
                 traffic = tj.get("hbm_bytes_per_launch", {}).get(dom)
+        t_kernels = t_stats + t_apply
         roof = {"bound": "hbm", "kernel": dom, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": ach / HBM_PEAK, "traffic": traffic,
-                "limiter": "vector-instruction issue (~4 cycles per instruction and SIMD, DESIGN.md 4.1): the sweep is priced by its "
-                           "instruction count, not by its bytes; HBM traffic == algorithmic bytes",
+                "traffic_source": "profiles/r03_traffic.json (rocprofv3 --pmc passes of this command; not live)" if traffic else None,
                 "algorithmic_bytes_per_launch": kern[dom]["bytes"],
-                "algorithmic_bytes_note": "%d float32 planes x %d pairs: target read + result write%s" % (
-                    apply_planes if dom == k_apply else 2, B,
-                    " + ground-truth read of the fused per-frame PSNR" if (dom == k_apply and apply_planes == 3) else
-                    ("" if dom == k_apply else " (statistics sweep: target + reference read)")),
+                "algorithmic_bytes_note": "2 float32 planes x %d pairs (SURVEY 8d): %s" % (
+                    B, "target read + result write" if dom == k_apply else "target + reference read"),
                 "avg_launch_s": kern[dom]["t"],
-                # the same launch priced on the transfer's two planes only (as if the ground-truth read of the fused PSNR were free)
-                "frac_transfer_planes_only": 2 * B * PLANE_F32 / kern[dom]["t"] / HBM_PEAK,
+                "frac_with_metric_plane": (kern[dom]["bytes"] + kern[dom]["extra"]) / kern[dom]["t"] / HBM_PEAK,
                 "lab_arithmetic": ct_hip.lab_mode(),
-                "kernels": {k: {"GB/s": v["bytes"] / v["t"] / 1e9, "avg_launch_us": v["t"] * 1e6,
-                                "algorithmic_bytes_per_launch": v["bytes"]} for k, v in kern.items()},
+                "kernels": {k: {"GB/s": v["bytes"] / v["t"] / 1e9, "frac": v["bytes"] / v["t"] / HBM_PEAK, "avg_launch_us": v["t"] * 1e6,
+                                "algorithmic_bytes_per_launch": v["bytes"],
+                                "GB/s_with_metric_plane": (v["bytes"] + v["extra"]) / v["t"] / 1e9} for k, v in kern.items()},
                 "path": {"algorithmic_bytes_per_pair": ALGO_BYTES_PER_PAIR,
                          "GB/s": ALGO_BYTES_PER_PAIR * value / world / 1e9,
                          "frac_of_peak": ALGO_BYTES_PER_PAIR * value / world / HBM_PEAK,
-                         "frac_of_peak_with_metric_plane": (ALGO_BYTES_PER_PAIR + (PLANE_F32 if apply_planes == 3 else 0)) * value / world / HBM_PEAK,
-                         "note": "value includes the per-frame metric kernels (%s) in the timed region" % (",".join(names) or "none")}}
+                         "sum_of_event_timed_kernels_ms": t_kernels * 1e3,
+                         "note": "3 compulsory planes per pair over the whole step; value includes the per-frame metric (%s)" % (",".join(names) or "none")}}
+        # consistency of the timed region with the kernels it is made of (PSNR-only mode: two sweeps + a 5 us finish)
+        if fused_psnr and dt / K > 1.3 * t_kernels + 30e-6:
+            roof["warning"] = "ms_per_step %.3f exceeds 1.3 x the event-timed kernels (%.3f ms): host-side cost inside the timed region" % (
+                dt / K * 1e3, t_kernels * 1e3)
 
         if not args.no_extra and world == 1:        # informational rates of the other paths: single-GPU runs only
             def rate(fn, n=10):
@@ -313,10 +333,12 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "stereopairs/s at 1920x1080 (methods.linear.color_transfer_between_images)",
+            "metric": BASELINE_METRIC,
             "value": value, "unit": "stereopairs/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE[ct_hip.lab_mode()], "data": "synthetic",
+            # the other half of BASELINE.json's metric: dcmcs3di forward at 1920x1080 on the same GPU (details: roofline_cnn)
+            "value_cnn": roof_cnn["pairs_per_s"] if roof_cnn else None, "unit_cnn": "stereopairs/s (dcmcs3di fwd, 1920x1080)",
             "config": {"workload": "configs[1]: methods.linear.color_transfer_between_images (Reinhard) on "
                                    "1920x1080 synthetic float32 RGB pairs, HBM-resident; apply sweep float64-grade, "
                                    "statistics sweep float32 (the reference's own precision for float32 frames); "

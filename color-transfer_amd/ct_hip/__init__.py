@@ -18,6 +18,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CT_HIP_LIB") or os.path.join(_HERE, "libct_hip.so")   # CT_HIP_LIB: tuning builds only
 
+CT_ABI_VERSION = 3            # include/ct_hip.h: CT_ABI_VERSION; lib() refuses any other library
 CT_LAB_STATS_STRIDE = 8
 CT_RGB_STATS_STRIDE = 16
 CT_WS_LAB_STATS, CT_WS_RGB_MEANCOV, CT_WS_REINHARD, CT_WS_IDT, CT_WS_REINHARD_PSNR = 0, 1, 2, 3, 4
@@ -94,6 +95,10 @@ def lib():
                     fn = getattr(handle, name)  # AttributeError = ABI mismatch, also loud
                     fn.restype = res
                     fn.argtypes = args
+                got = handle.ct_abi_version()
+                if got != CT_ABI_VERSION:            # a stale build (or CT_HIP_LIB) would misread every changed argument list
+                    raise CtHipError("%s reports ABI version %d, this binding needs %d: rebuild with `make -C color-transfer_amd/csrc`"
+                                     % (LIB_PATH, got, CT_ABI_VERSION))
                 _lib = handle
     return _lib
 

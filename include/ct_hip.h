@@ -33,7 +33,9 @@ extern "C" {
 #define CT_E_WORKSPACE (-2)  /* workspace too small / misaligned */
 #define CT_E_ALIGN (-3)      /* image base not aligned to its element size */
 
-#define CT_ABI_VERSION 1
+/* bumped whenever an entry point changes its argument list (2: ct_attention_tokens_f32 gained kv_shift; 3: round 3);
+ * the ctypes binding refuses a library whose ct_abi_version() differs */
+#define CT_ABI_VERSION 3
 
 /* doubles per image in a stats record written by ct_lab_stats / ct_rgb_meancov */
 #define CT_LAB_STATS_STRIDE 8  /* mean[3], std[3] (population, ddof 0), n, 0           */
