@@ -17,56 +17,14 @@
 // transpose) as in cnn.hip.  Requires W % 4 == 0 and 16-byte aligned tensors; other cases stay on the f32 kernel.
 #include "ct_common.h"
 #include "ct_conv.h"
+#include "ct_split.h"
 
 namespace ct {
-
-typedef float f32x16s __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kSpTH = 8;      // output rows per workgroup (two per wave)
 constexpr int kSpTW = 32;     // output columns per workgroup (= MFMA N)
 constexpr int kSpKC = 16;     // input channels per stage (= MFMA K)
 constexpr int kSpCUs = 256;
-
-template <bool GEN>
-__device__ __forceinline__ float split_act(float v, int act) {
-    if (!GEN) return v > 0.f ? v : 0.01f * v;
-    switch (act) {
-        case 1: return v > 0.f ? v : 0.01f * v;
-        case 2: return v > 0.f ? v : 0.f;
-        case 3: return 1.0f / (1.0f + expf(-v));
-        case 4: return tanhf(v);
-        case 5: return v / (1.0f + expf(-v));        // swish
-        default: return v;
-    }
-}
-
-// x -> (hi, mid, lo) bf16 bit patterns; hi + mid + lo == x up to 2^-24 relative.  NaN stays NaN; an infinity becomes
-// (inf, NaN, NaN), i.e. an infinite activation yields NaN outputs where the f32 kernel yields +-inf / NaN.
-__device__ __forceinline__ void split3(float x, unsigned int &h, unsigned int &m, unsigned int &l) {
-    const __bf16 bh = (__bf16)x;
-    const float r1 = x - (float)bh;
-    const __bf16 bm = (__bf16)r1;
-    const float r2 = r1 - (float)bm;
-    const __bf16 bl = (__bf16)r2;
-    h = __builtin_bit_cast(unsigned short, bh);
-    m = __builtin_bit_cast(unsigned short, bm);
-    l = __builtin_bit_cast(unsigned short, bl);
-}
-
-// two values at once, packed (x0 in the low half): one v_cvt_pk_bf16_f32 per piece, halves re-expanded by shift / mask
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned int pack_bf16(float a, float b) {
-    f32x2 v = {a, b};
-    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ void split3x2(float x0, float x1, unsigned int &hw, unsigned int &mw, unsigned int &lw) {
-    hw = pack_bf16(x0, x1);
-    const float r0 = x0 - __uint_as_float(hw << 16), r1 = x1 - __uint_as_float(hw & 0xffff0000u);
-    mw = pack_bf16(r0, r1);
-    lw = pack_bf16(r0 - __uint_as_float(mw << 16), r1 - __uint_as_float(mw & 0xffff0000u));
-}
 
 // LDS-DMA: 64 lanes x 16 bytes from global straight into LDS at lds_addr + 16 * lane (no registers).  Issued through
 // inline asm on purpose: behind the builtin the compiler puts an s_waitcnt vmcnt(0) in front of every later LDS read
@@ -452,6 +410,10 @@ int conv_split(const ConvArgs &a, int N, int kh, int kw, bool gen, hipStream_t s
                      ((reinterpret_cast<uintptr_t>(a.wp) & 15) == 0) &&
                      (!a.residual || (((reinterpret_cast<uintptr_t>(a.residual) & 15) == 0) && (a.res_bstride % 4 == 0)));
     if (!vec) return 1;
+    if (kh == 3 && kw == 3) {
+        const int rc = conv_ws(a, N, gen, s);
+        if (rc != 1) return rc;
+    }
     if (gen) {
         if (kh == 3 && kw == 3) return launch_split<3, 3, true>(a, N, s);
         if (kh == 1 && kw == 1) return launch_split<1, 1, true>(a, N, s);

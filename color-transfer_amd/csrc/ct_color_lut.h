@@ -163,11 +163,21 @@ __device__ __forceinline__ float expand32(const unsigned char *lds, float c) {
 
 // cube root of a float32 in [2^-7, 2): quadratic around the nearest of 128 nodes per octave
 __device__ __forceinline__ float cbrt32(const unsigned char *lds, float v) {
+#ifdef CT_STATS_CBRT_HW
+    // no look-up: r ~ v^(-1/3) from the hardware log2 / exp2 (~5e-7 relative), y0 = v r^2, one correction step in the
+    // residual g = y0 r = v r^3: y = y0 g^(-2/3) ~ y0 (1 + 2/3 (1 - g)); the residual comes out of one fma exactly, so what
+    // is left is a third of y0's two roundings plus the final one (< 8e-8 relative, symmetric)
+    const float r = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(v) * (-1.0f / 3.0f));
+    const float u = (v * r) * r;
+    const float e = fmaf(-u, r, 1.0f);
+    return fmaf(u * (2.0f / 3.0f), e, u);
+#else
     const uint32_t bits = __float_as_uint(v) + (1u << (22 - kB32Bits));
     const uint32_t off = (bits >> (19 - kB32Bits)) & (((8u << kB32Bits) - 1u) << 4);
     const float4 e = *reinterpret_cast<const float4 *>(lds + kLdsB + CT_LUT_OFF(off, 16));      // {c, s1, s2, node}
     const float d = v - e.w;                                                    // exact
     return fmaf(d, fmaf(d, e.z, e.y), e.x);
+#endif
 }
 
 // matrix row in float32 with two-piece constants: a constant rounded to float32 is off by up to 3e-8 relative for EVERY

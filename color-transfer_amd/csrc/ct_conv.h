@@ -19,10 +19,15 @@ struct ConvArgs {
     int clamp;   // 1 = clamp to [0,1]
     int groups;  // output-channel groups of MT*32 (weights packed group-major); 1 for cout <= 64
     unsigned long long *prof;   // diagnostic builds only (CT_CONV_PROFILE); NULL otherwise
+    int n_images = 0;           // conv_ws only (set by its launcher)
 };
 
 // cnn.hip: stride-1, padding k/2, kernel 3x3 / 1x1 / 1x5 / 5x1, weights packed [group][tap][cin_pair][2][64];
 // returns CT_OK / an error, or 1 if (kh, kw) has no LDS-tiled kernel
 int conv_fast(const ConvArgs &a, int N, int kh, int kw, hipStream_t s);
+
+// conv_ws.hip: 3x3, 32 < cin <= 64, one input tensor: weights stationary in registers, contraction split across the waves;
+// returns CT_OK / an error, or 1 if the geometry is not this kernel's
+int conv_ws(const ConvArgs &a, int N, bool gen, hipStream_t s);
 
 }  // namespace ct

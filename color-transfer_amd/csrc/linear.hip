@@ -364,10 +364,16 @@ __global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_STATS) void lab_moments_lut_k
 #if CT_LUT_PREFETCH
     float nxt[12];
 #endif
+#if CT_LUT_PREFETCH == 2
+    float nx2[12];
+#endif
 #ifdef CT_DIAG_CLOCK      // diagnostic build: shader clock held during this kernel = d(s_memtime) / d(s_memrealtime) x 100 MHz
     const uint64_t clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     if (t < n_full) load_tile(p + t * (kTilePixels * 3), lane, cur);          // in flight while the tables are copied
+#if CT_LUT_PREFETCH == 2
+    if (t + stride < n_full) load_tile(p + (t + stride) * (kTilePixels * 3), lane, nxt);
+#endif
     float p0[3] = {0.f, 0.f, 0.f};
     if (threadIdx.x == 0 && n_pixels > 0) { p0[0] = p[0]; p0[1] = p[1]; p0[2] = p[2]; }
     lut::load_tables_f32<kLutBlock>(tab);
@@ -392,8 +398,19 @@ __global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_STATS) void lab_moments_lut_k
     double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     float sf[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (; t < n_full; t += stride) {
-#if CT_LUT_PREFETCH
+#if CT_LUT_PREFETCH == 2
+        if (t + 2 * stride < n_full) load_tile(p + (t + 2 * stride) * (kTilePixels * 3), lane, nx2);
+#elif CT_LUT_PREFETCH
+#ifdef CT_ABL_NOLOAD
+        if (t == (int64_t)blockIdx.x * kLutWaves + (threadIdx.x >> 6))
+#endif
         if (t + stride < n_full) load_tile(p + (t + stride) * (kTilePixels * 3), lane, nxt);
+#endif
+#ifdef CT_ABL_NOMATH
+        if (true) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { sf[0] += cur[3 * q]; sf[1] += cur[3 * q + 1]; sf[2] += cur[3 * q + 2]; }
+        } else
 #endif
 #ifdef CT_ABL_NOSLOW
         if (false) {
@@ -418,7 +435,10 @@ __global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_STATS) void lab_moments_lut_k
                 sf[3] = fmaf(dx, dx, sf[3]); sf[4] = fmaf(dy, dy, sf[4]); sf[5] = fmaf(dz, dz, sf[5]);
             }
         }
-#if CT_LUT_PREFETCH
+#if CT_LUT_PREFETCH == 2
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { cur[i] = nxt[i]; nxt[i] = nx2[i]; }
+#elif CT_LUT_PREFETCH
 #pragma unroll
         for (int i = 0; i < 12; ++i) cur[i] = nxt[i];
 #else
@@ -524,9 +544,22 @@ __global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_APPLY) void reinhard_apply_lu
     __syncthreads();
     for (; t < n_full; t += stride) {
 #if CT_LUT_PREFETCH
+#ifdef CT_ABL_NOLOAD
+        if (t == (int64_t)blockIdx.x * kLutWaves + (threadIdx.x >> 6))
+#endif
         if (t + stride < n_full) load_tile(p + (t + stride) * (kTilePixels * 3), lane, nxt);
 #endif
         float w[12];
+#ifdef CT_APPLY_GT_EARLY
+        float gv[12];
+        if (gt != nullptr) load_tile(gt + ((size_t)img * n_pixels + (size_t)t * kTilePixels) * 3, lane, gv);
+#endif
+#ifdef CT_ABL_NOMATH
+        if (true) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) w[i] = cur[i] * (float)c.sL;
+        } else
+#endif
 #ifdef CT_ABL_NOSLOW
         if (false) {
 #else
@@ -556,10 +589,19 @@ __global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_APPLY) void reinhard_apply_lu
                 }
             }
         }
+#ifdef CT_ABL_NOSTORE
+        if (w[0] == 123.456f)
+#endif
         store_tile(o + t * (kTilePixels * 3), lane, w);
+#ifdef CT_ABL_NOGT
+        if (false) {
+#else
         if (gt != nullptr) {
+#endif
+#ifndef CT_APPLY_GT_EARLY
             float gv[12];
             load_tile(gt + ((size_t)img * n_pixels + (size_t)t * kTilePixels) * 3, lane, gv);
+#endif
             float e = 0.f;
 #pragma unroll
             for (int i = 0; i < 12; ++i) { const float d = w[i] - gv[i]; e = fmaf(d, d, e); }

@@ -12,15 +12,17 @@ from tests.gmflow_common import procedural_state, test_pair as make_pair   # noq
 
 
 # asserted per-stage bounds (pixels for the flow stages), per convolution mode; see test_gmflow_vs_reference
-STAGE_BOUNDS = {   # measured round 2 (worst of the two goldens): see the comment row under each bound
-    "split": {"backbone 1/8": 7e-5, "backbone 1/4": 7e-5, "transformer s0": 1.1e-4, "global match": 3.2e-3, "propagation s0": 1.6e-4,
-              # measured      3.2e-5               3.1e-5                  5.2e-5                 1.55e-3                  7.6e-5
-              "transformer s1": 3.5e-4, "local match": 1.5e-2, "propagation s1": 6.5e-3, "refine": 7e-3, "flow": 5e-2, "flow_bwd": 2.5e-2},
-    #          measured 1.6e-4              7.1e-3                  3.1e-3                   3.3e-3        2.3e-2        1.2e-2
-    "exact": {"backbone 1/8": 7e-5, "backbone 1/4": 7e-5, "transformer s0": 1.1e-4, "global match": 2.4e-3, "propagation s0": 1.6e-4,
-              # measured      3.0e-5               3.1e-5                  4.2e-5                 1.2e-3                   6.2e-5
-              "transformer s1": 4.1e-4, "local match": 8e-3, "propagation s1": 7e-3, "refine": 7.1e-3, "flow": 5e-2, "flow_bwd": 2.2e-2},
-    #          measured 2.0e-4              3.8e-3                3.4e-3                  3.5e-3          2.3e-2        1.1e-2
+STAGE_BOUNDS = {   # 2x the worst value measured on MI355X in rounds 2 and 3 (worst of the two goldens): see the comment row under each bound
+    "split": {"backbone 1/8": 7e-5, "backbone 1/4": 7e-5, "transformer s0": 1.1e-4, "global match": 3.2e-3, "propagation s0": 3.3e-4,
+              # measured      3.2e-5               3.1e-5                  5.2e-5                 1.55e-3                  1.65e-4
+              "transformer s1": 4.6e-4, "local match": 1.5e-2, "propagation s1": 1.1e-2, "refine": 1.1e-2, "flow": 5e-2, "flow_bwd": 2.5e-2},
+    #          measured 2.3e-4              7.1e-3                  5.4e-3                   5.4e-3        2.3e-2        1.2e-2
+    # (round 3: the 3x3 convolutions with <= 64 input channels sum per 16-channel chunk first (csrc/conv_ws.hip); the backbone
+    # got closer to the reference, 2.3e-5, the chaotic stages behind the global match moved within their float32 noise)
+    "exact": {"backbone 1/8": 7e-5, "backbone 1/4": 7e-5, "transformer s0": 1.1e-4, "global match": 2.4e-3, "propagation s0": 2.2e-4,
+              # measured      3.0e-5               3.1e-5                  4.2e-5                 1.3e-3                   1.1e-4
+              "transformer s1": 4.6e-4, "local match": 1e-2, "propagation s1": 7e-3, "refine": 7.1e-3, "flow": 5e-2, "flow_bwd": 2.9e-2},
+    #          measured 2.3e-4              4.9e-3                3.4e-3                  3.5e-3          2.3e-2        1.45e-2
 }
 
 

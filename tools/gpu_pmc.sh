@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT -- python3 $ROOT/$@ > $OUT/stdout.txt 2> $OUT/stderr.txt
+timeout 300 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT -- python3 $ROOT/$@ > $OUT/stdout.txt 2> $OUT/stderr.txt
 cd $ROOT
 python3 - "$OUT" <<'PY'
 import csv, glob, os, sys

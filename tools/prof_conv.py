@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(ROOT, "color-transfer_amd"))
 import numpy as np
 import torch
 import ct_hip
-lib = ctypes.CDLL(os.path.join(ROOT, "color-transfer_amd", "csrc", "build", "libct_conv_prof.so"))
+lib = ctypes.CDLL(os.path.join(ROOT, "color-transfer_amd", "ct_hip", "libct_conv_prof.so"))
 P = ctypes.c_void_p
 lib.ct_conv2d_prof_f32.argtypes = [P, P, P, P, P] + [ctypes.c_int] * 5 + [P, P]
 N, C, H, W = 2, 64, int(sys.argv[1]) if len(sys.argv) > 1 else 512, int(sys.argv[2]) if len(sys.argv) > 2 else 512
