@@ -20,6 +20,8 @@ struct ConvArgs {
     int groups;  // output-channel groups of MT*32 (weights packed group-major); 1 for cout <= 64
     unsigned long long *prof;   // diagnostic builds only (CT_CONV_PROFILE); NULL otherwise
     int n_images = 0;           // conv_ws only (set by its launcher)
+    int f16 = 0;                // conv_ws only: 1 = two fp16 pieces (weights scaled by 2^w_exp), 0 = three bf16 pieces
+    int w_exp = 0;
 };
 
 // cnn.hip: stride-1, padding k/2, kernel 3x3 / 1x1 / 1x5 / 5x1, weights packed [group][tap][cin_pair][2][64];

@@ -534,6 +534,18 @@ SIGNATURES.update({
 #          accuracy, 2.67x the matrix rate).  "exact": v_mfma_f32_32x32x2_f32, bitwise an fmaf chain (csrc/cnn.hip).
 # Geometries the split kernel does not cover (stride 2, 7x7, W % 4 != 0, unaligned views) always run "exact".
 _conv_mode = os.environ.get("CT_HIP_CONV", "split")
+# split mode, 3x3 convolutions with 32 < cin <= 64 (the ResB convs): two fp16 pieces / three MFMAs per product on the
+# weight-stationary kernel (csrc/conv_ws.hip) instead of three bf16 pieces / six MFMAs; CT_HIP_CONV_WS16=0 switches it off
+_ws16 = os.environ.get("CT_HIP_CONV_WS16", "1") != "0"
+
+
+def set_conv_ws16(on):
+    global _ws16
+    _ws16 = bool(on)
+
+
+def conv_ws16():
+    return _ws16
 
 
 def set_conv_mode(mode):
@@ -569,6 +581,36 @@ def pack_conv_weight_split(weight, bias):
     return ws, b
 
 
+def pack_conv_weight_split16(weight):
+    """3x3 Conv2d weight (32 < cin <= 64) -> ct_conv3x3_ws16_f32 operand: fp16 bit patterns (int16)
+    [ceil(cout/64)][ceil(cin/16)][9][piece hi/lo][m 0..1][k-half 0..1][cout%32][8 channels] of weight * 2^w_exp, and w_exp
+    (the largest |weight| lands in [2^11, 2^12): both pieces of all but the tiniest weights are normal fp16 numbers)."""
+    cout, cin, kh, kw = weight.shape
+    g, nc = (cout + 63) // 64, (cin + 15) // 16
+    w = torch.zeros((g * 64, nc * 16, kh, kw), dtype=torch.float32, device=weight.device)
+    w[:cout, :cin] = weight.detach().float()
+    amax = float(w.abs().max())
+    w_exp = 0 if not (amax > 0 and amax < float("inf")) else 12 - (int(np.floor(np.log2(amax))) + 1)
+    w_exp = max(-100, min(100, w_exp))
+    ws = w * (2.0 ** w_exp)
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.float()).to(torch.float16)
+    pieces = torch.stack([hi, lo], dim=0).view(torch.int16)                # [2][coutp][cinp][kh][kw]
+    pieces = pieces.reshape(2, g, 2, 32, nc, 2, 8, kh * kw)                # piece, g, m, r, chunk, h, j, tap
+    return pieces.permute(1, 4, 7, 0, 2, 5, 3, 6).contiguous(), w_exp      # g, chunk, tap, piece, m, h, r, j
+
+
+def _ws16_ok(x, split, kh, kw):
+    return _ws16 and (kh, kw) == (3, 3) and 32 < x.shape[1] <= 64 and len(split) > 2 and split[2] is not None
+
+
+def _split_operands(weight, bias):
+    """(bf16 pieces, padded bias, fp16 image or None): what travels with a packed convolution weight as `_ct_split`"""
+    cout, cin, kh, kw = weight.shape
+    w16 = pack_conv_weight_split16(weight) if (kh, kw) == (3, 3) and 32 < cin <= 64 else None
+    return pack_conv_weight_split(weight, bias) + (w16,)
+
+
 def _split_ok(x, out, residual, kh, kw, stride, ph, pw):
     if _conv_mode != "split" or stride != 1 or (kh, kw) not in ((3, 3), (1, 1), (1, 5), (5, 1)) or (ph, pw) != (kh // 2, kw // 2):
         return False
@@ -581,10 +623,15 @@ def _split_ok(x, out, residual, kh, kw, stride, ph, pw):
 
 
 def _conv_split(x, split, cout, kh, kw, act, residual, clamp, out, x2=None):
-    ws, b64 = split
+    ws, b64 = split[0], split[1]
     n, cin1, h, w = x.shape
     cin = cin1 + (x2.shape[1] if x2 is not None else 0)
     rs = _nchw_bstride(residual) if residual is not None else 0
+    if x2 is None and _ws16_ok(x, split, kh, kw):
+        w16, w_exp = split[2]
+        check(lib().ct_conv3x3_ws16_f32(_ptr(x), _ptr(w16), int(w_exp), _ptr(b64), _opt(residual), _ptr(out), n, cin, cout, h, w,
+                                        _nchw_bstride(x), _nchw_bstride(out), rs, int(act), int(bool(clamp)), _stream()))
+        return out
     check(lib().ct_conv2d_split_f32(_ptr(x), _opt(x2), cin1, _ptr(ws), _ptr(b64), _opt(residual), _ptr(out), n, cin, cout, h, w,
                                     kh, kw, _nchw_bstride(x), _nchw_bstride(x2) if x2 is not None else 0, _nchw_bstride(out),
                                     rs, int(act), int(bool(clamp)), _stream()))
@@ -604,7 +651,7 @@ def pack_conv_weight(weight, bias):
     b = torch.zeros(coutp, dtype=torch.float32, device=weight.device)
     if bias is not None:
         b[:cout] = bias.detach().float()
-    wp._ct_split = pack_conv_weight_split(weight, bias)      # operands of the split-bf16 kernel travel with the packing
+    wp._ct_split = _split_operands(weight, bias)      # operands of the split kernels travel with the packing
     return wp, b
 
 
@@ -675,6 +722,7 @@ def pam_valid(q, k, want_att=False):
 _c_f = ctypes.c_float
 SIGNATURES.update({
     "ct_gconv2d_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 10 + [_c_ll, _c_ll, _c_int, _c_p]),
+    "ct_conv3x3_ws16_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p] + [_c_int] * 5 + [_c_ll, _c_ll, _c_ll, _c_int, _c_int, _c_p]),
     "ct_instance_norm_workspace_bytes": (ctypes.c_size_t, [_c_int]),
     "ct_instance_norm_f32": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_f, _c_int, _c_p, ctypes.c_size_t, _c_p]),
     "ct_eltwise_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_f, _c_p]),
@@ -728,7 +776,7 @@ def pack_gconv_weight(weight, bias):
     if bias is not None:
         b[:cout] = bias.detach().float()
     if kh * kw <= 9:
-        wp._ct_split = pack_conv_weight_split(weight, bias)
+        wp._ct_split = _split_operands(weight, bias)
     return wp, b
 
 

@@ -242,6 +242,16 @@ int ct_conv2d_split_f32(const float *in, const float *in2, int cin1, const void 
                         int kw, long long in_bstride, long long in2_bstride, long long out_bstride,
                         long long res_bstride, int act, int clamp, void *stream);
 
+/* The ResB convolutions (3x3, stride 1, padding 1, 32 < cin <= 64; reference pasmnet/backbone.py:8-15, unimatch/backbone.py
+ * residual blocks) on the weight-stationary kernel of csrc/conv_ws.hip with float32 operands as TWO fp16 pieces and three
+ * v_mfma_f32_32x32x16_f16 per 16-channel product (float32 accumulation; 2^-22 relative is dropped: float32-grade, not bitwise
+ * the fmaf chain).  Every staged input row is scaled by a power of two of its own, the weights by 2^w_exp, so any finite
+ * float32 input is in range.  wp16: fp16 bit patterns [ceil(cout/64)][ceil(cin/16)][9][piece hi/lo][m][k-half][cout%32][8]
+ * of weight * 2^w_exp; bias zero-padded to 64 * ceil(cout/64); act / clamp / residual as ct_conv2d_split_f32. */
+int ct_conv3x3_ws16_f32(const float *in, const void *wp16, int w_exp, const float *bias, const float *residual, float *out, int n,
+                        int cin, int cout, int h, int w, long long in_bstride, long long out_bstride, long long res_bstride, int act,
+                        int clamp, void *stream);
+
 /* Parallax attention, one direction (pasmnet/attention.py:39-41, utils.py:30, utils.py:123-125):
  *   P = softmax_j( sum_c q[c][h][i] k[c][h][j] / c ) ;  out_v[c][h][i] = sum_j P[i][j] v[c][h][j],
  *   out_rgb likewise for the 3 channels of `rgb` (dcmcs3di.py:58,65).  att: NULL, or [n][h][w][w]
