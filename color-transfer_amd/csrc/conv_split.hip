@@ -65,7 +65,19 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
     const size_t plane = (size_t)a.H * a.W;
     const unsigned int uplane = (unsigned int)plane;
     const int n_chunks = (a.cin + kSpKC - 1) / kSpKC;
-    const int my_tiles = (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    // XCD-aware tile order (round 3): workgroup b runs on XCD b % 8 (round-robin dispatch; an assumption that only costs
+    // speed if wrong); XCD p walks the contiguous range [p T, (p + 1) T) of the row-major (tile, group) list with its
+    // workgroups side by side, so the halo columns / rows of a tile -- the edge lines of its neighbours -- are found in the
+    // same L2 instead of being pulled through the fabric once per tile (conv_ws.hip measured 3 lines per line of new data).
+    const bool xcd_order = (gridDim.x & 7) == 0 && n_tiles >= (int)gridDim.x;
+    const int tiles_per_xcd = (n_tiles + 7) >> 3, wgs_per_xcd = (int)gridDim.x >> 3;
+    const int xcd_first = (int)(blockIdx.x & 7) * tiles_per_xcd;
+    const int xcd_count = max(0, min(tiles_per_xcd, n_tiles - xcd_first));
+    const int my_tiles = xcd_order ? (xcd_count - (int)(blockIdx.x >> 3) + wgs_per_xcd - 1) / wgs_per_xcd
+                                   : (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    auto tile_id = [&](int k) -> int {            // this workgroup's k-th (tile, group) index
+        return xcd_order ? xcd_first + (int)(blockIdx.x >> 3) + k * wgs_per_xcd : (int)blockIdx.x + k * (int)gridDim.x;
+    };
     const int n_stages = my_tiles * n_chunks;
     if (n_stages == 0) return;
 
@@ -76,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
     float pfe[PFE > 0 ? PFE : 1];
     auto fetch_tile = [&](int stage) {
         const int k = stage / n_chunks, chunk = stage - k * n_chunks;
-        const int t = (blockIdx.x + k * gridDim.x) / a.groups;
+        const int t = tile_id(k) / a.groups;
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
         const int x0 = tx * kSpTW, y0 = ty * kSpTH, c0 = chunk * kSpKC;
         // two-source input: a 16-channel chunk lies entirely in one of the tensors (cin1 % 16 == 0)
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
     const unsigned int wl_addr = (unsigned int)reinterpret_cast<uintptr_t>(wl);   // LDS byte address (low half of the flat address)
     const int n_gtaps = n_stages * TAPS;
     // issue cursor (taps are issued strictly in order, so no divisions): tap within the stage, chunk, group, ring slot
-    int wi_tap = 0, wi_chunk = 0, wi_k = 0, wi_grp = (int)(blockIdx.x % a.groups), wi_slot = 0;
+    int wi_tap = 0, wi_chunk = 0, wi_k = 0, wi_grp = (int)(tile_id(0) % a.groups), wi_slot = 0;
     auto w_issue = [&](int /*g*/) {
         const uint4 *src = wp16 + ((((size_t)wi_grp * n_chunks + wi_chunk) * TAPS + wi_tap) * 3 * MT) * 64 + lane;
         const unsigned int dst = wl_addr + (unsigned int)(wi_slot * WSLOT * 16);   // + 16 * lane is implied by the instruction
@@ -177,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
             if (++wi_chunk == n_chunks) {
                 wi_chunk = 0;
                 ++wi_k;
-                wi_grp = (int)((blockIdx.x + wi_k * gridDim.x) % a.groups);
+                wi_grp = (int)(tile_id(wi_k) % a.groups);
             }
         }
     };
@@ -209,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
     }
     const bool res_in_acc = (a.residual != nullptr) && (a.act == 0);
     auto init_acc = [&](int k) {   // raw float4 rows of the skip tensor (or zeros); finish_acc() re-lays them out
-        const int tg = blockIdx.x + k * gridDim.x, t = tg / a.groups, grp = tg - t * a.groups;
+        const int tg = tile_id(k), t = tg / a.groups, grp = tg - t * a.groups;
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
         const float *__restrict__ res = res_in_acc ? a.residual + (size_t)n * a.res_bstride + (size_t)grp * COUTP * plane : nullptr;
         const int cout_g = a.cout - grp * COUTP;
@@ -257,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
     store_tile();
     for (int stage = 0; stage < n_stages; ++stage) {
         const int k = stage / n_chunks, chunk = stage - k * n_chunks;
-        const int grp = (int)((blockIdx.x + k * gridDim.x) % a.groups);
+        const int grp = (int)(tile_id(k) % a.groups);
         if (chunk == 0) {
             finish_acc();
 #pragma unroll
@@ -331,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
         }
         if (chunk + 1 == n_chunks) {
             // ---- epilogue: lane owns pixels (y0 + wave*RPW + q, x0+nl), channels (r&3)+8(r>>2)+4hl of each 32-tile ----
-            const int t = (blockIdx.x + k * gridDim.x) / a.groups;
+            const int t = tile_id(k) / a.groups;
             const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
             float *__restrict__ out = a.out + (size_t)n * a.out_bstride + (size_t)grp * COUTP * plane;
             const float *__restrict__ res = a.residual ? a.residual + (size_t)n * a.res_bstride + (size_t)grp * COUTP * plane : nullptr;

@@ -290,6 +290,11 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs a, int n_strip
                     make_float4(rvv[0], rvv[1], rvv[2], rvv[3]);
         };
         auto reduce_row = [&](int r, const float4 &rv) { reduce_issue(r); reduce_compute(rv); reduce_store(r); };
+#ifdef CT_WS_ABL_NOREDUCE
+#define reduce_issue(r) do { } while (0)
+#define reduce_compute(rv) do { rvv[0] = rv.x; } while (0)
+#define reduce_store(r) do { } while (0)
+#endif
         // X(r): finish output row r-1, the MFMAs of output row y0 + r on this wave's (chunk, half) block, partial sums -> LDS.
         auto phase_x = [&](int r, const float4 &rv) {
             reduce_issue(r - 1);
@@ -334,7 +339,13 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs a, int n_strip
                     if constexpr (F16) {
                         const f16x8 bh = __builtin_bit_cast(f16x8, bq[ky][kx][0]), bl = __builtin_bit_cast(f16x8, bq[ky][kx][1]);
                         const f16x8 ah = __builtin_bit_cast(f16x8, wreg[tap][0]), al = __builtin_bit_cast(f16x8, wreg[tap][1]);
+#ifdef CT_WS_ABL_NOMFMA
+                        if (tap == 4) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+                        else { acc[0] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, bl).y) + __builtin_bit_cast(float, __builtin_bit_cast(uint4, ah).x); }
+                        if (false) {
+#else
                         if (tap & 1) {
+#endif
                             acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2, 0, 0, 0);
                             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
                             acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc2, 0, 0, 0);
@@ -373,6 +384,9 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs a, int n_strip
             float unscale = 1.f;
             if constexpr (F16) unscale = __uint_as_float((unsigned int)(127 + min(max(-e_cur - a.w_exp, -126), 127)) << 23);
 #pragma unroll
+#ifdef CT_WS_ABL_NOPART
+            if (acc[0] == 123.456f)
+#endif
             for (int i = 0; i < 16; ++i) pw[((i & 3) + 8 * (i >> 2) + 4 * hl) * kWsPS] = F16 ? (acc[i] + acc2[i]) * unscale : acc[i] + acc2[i];
         };
         auto phase_x_full = [&](int r, auto set_c) {

@@ -36,12 +36,13 @@ static std::mutex g_exec_mutex;     // a cached hipFFT plan carries its stream a
 
 // plans for `batch` luminance images (forward) and batch * 16 filtered spectra (inverse); work area supplied per call.
 // Returns a COPY of the cache entry (handles are plain values; the table may be reshuffled by the next call).
+// Callers hold g_exec_mutex from before this call until their last hipFFT call (lock order: exec, then plan).
 static bool fsim_plan(int hp, int wp, int batch, FsimPlan *out) {
     std::lock_guard<std::mutex> lock(g_plan_mutex);
     for (int i = 0; i < g_n_plans; ++i)
         if (g_plans[i].hp == hp && g_plans[i].wp == wp && g_plans[i].batch == batch) { *out = g_plans[i]; return true; }
-    if (g_n_plans == kFsMaxPlans) {                // recycle the oldest entry; its transforms may still be in flight
-        (void)hipDeviceSynchronize();
+    if (g_n_plans == kFsMaxPlans) {                // recycle the oldest entry; its transforms may still be in flight.  The
+        (void)hipDeviceSynchronize();              // caller holds g_exec_mutex, so no other thread is between look-up and execute
         hipfftDestroy(g_plans[0].fwd);
         hipfftDestroy(g_plans[0].inv);
         for (int i = 1; i < kFsMaxPlans; ++i) g_plans[i - 1] = g_plans[i];
@@ -51,11 +52,16 @@ static bool fsim_plan(int hp, int wp, int batch, FsimPlan *out) {
     p.hp = hp; p.wp = wp; p.batch = batch;
     int n[2] = {hp, wp};
     size_t w1 = 0, w2 = 0;
-    if (hipfftCreate(&p.fwd) != HIPFFT_SUCCESS || hipfftCreate(&p.inv) != HIPFFT_SUCCESS) return false;
+    if (hipfftCreate(&p.fwd) != HIPFFT_SUCCESS) return false;
+    if (hipfftCreate(&p.inv) != HIPFFT_SUCCESS) { hipfftDestroy(p.fwd); return false; }
     hipfftSetAutoAllocation(p.fwd, 0);
     hipfftSetAutoAllocation(p.inv, 0);
-    if (hipfftMakePlanMany(p.fwd, 2, n, nullptr, 1, hp * wp, nullptr, 1, hp * wp, HIPFFT_C2C, batch, &w1) != HIPFFT_SUCCESS) return false;
-    if (hipfftMakePlanMany(p.inv, 2, n, nullptr, 1, hp * wp, nullptr, 1, hp * wp, HIPFFT_C2C, batch * kFsK, &w2) != HIPFFT_SUCCESS) return false;
+    if (hipfftMakePlanMany(p.fwd, 2, n, nullptr, 1, hp * wp, nullptr, 1, hp * wp, HIPFFT_C2C, batch, &w1) != HIPFFT_SUCCESS ||
+        hipfftMakePlanMany(p.inv, 2, n, nullptr, 1, hp * wp, nullptr, 1, hp * wp, HIPFFT_C2C, batch * kFsK, &w2) != HIPFFT_SUCCESS) {
+        hipfftDestroy(p.fwd);                      // no handle leaks when a plan cannot be made
+        hipfftDestroy(p.inv);
+        return false;
+    }
     p.work = w1 > w2 ? w1 : w2;
     g_plans[g_n_plans++] = p;
     *out = p;
@@ -364,6 +370,7 @@ size_t ct_fsim_workspace_bytes(int batch, int h, int w) {
     if (batch < 1 || h < 1 || w < 1) return 0;
     const int f = ct::fsim_factor(h, w), hp = h / f, wp = w / f;
     if (hp < 2 || wp < 2) return 0;
+    std::lock_guard<std::mutex> exec_lock(ct::g_exec_mutex);    // plan creation may evict a plan another thread is about to run
     ct::FsimPlan pl, ps;
     if (!ct::fsim_plan(hp, wp, 2 * batch, &pl)) return 0;
     if (!ct::fsim_plan(hp, wp, 1, &ps)) return 0;            // the setup call runs the 16-image inverse plan of batch 1
@@ -376,13 +383,13 @@ int ct_fsim_setup_f32(int h, int w, float *filters, double *consts, void *ws, si
     if (!filters || !consts || !ws || h < 1 || w < 1 || (reinterpret_cast<uintptr_t>(ws) & 255)) return CT_E_BADARG;
     const int f = ct::fsim_factor(h, w), hp = h / f, wp = w / f, P = hp * wp;
     if (hp < 2 || wp < 2) return CT_E_BADARG;
+    std::lock_guard<std::mutex> exec_lock(ct::g_exec_mutex);
     ct::FsimPlan plan;
     if (!ct::fsim_plan(hp, wp, 1, &plan)) return CT_E_BADARG;
     const ct::FsimPlan *pl = &plan;
     const ct::FsimLayout l = ct::fsim_layout(ws, 2, P, pl->work);
     if (ws_bytes < l.total) return CT_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    std::lock_guard<std::mutex> exec_lock(ct::g_exec_mutex);
     hipLaunchKernelGGL(ct::fsim_filters_kernel, dim3((P + 255) / 256), dim3(256), 0, s, filters, hp, wp);
     CT_CHECK_LAUNCH();
     const size_t n = (size_t)ct::kFsK * P;
@@ -402,6 +409,7 @@ int ct_frame_fsim_f32(const float *a, const float *b, double *out, int batch, in
     if (batch == 0) return CT_OK;
     const int f = ct::fsim_factor(h, w), hp = h / f, wp = w / f, P = hp * wp, imgs = 2 * batch;
     if (hp < 2 || wp < 2 || imgs * ct::kFsO > 65535) return CT_E_BADARG;
+    std::lock_guard<std::mutex> exec_lock(ct::g_exec_mutex);
     ct::FsimPlan plan;
     if (!ct::fsim_plan(hp, wp, imgs, &plan)) return CT_E_BADARG;
     const ct::FsimPlan *pl = &plan;
@@ -410,7 +418,6 @@ int ct_frame_fsim_f32(const float *a, const float *b, double *out, int batch, in
     hipStream_t s = (hipStream_t)stream;
     const dim3 gp((P + 255) / 256, imgs);
     const float invP = 1.0f / (float)P;
-    std::lock_guard<std::mutex> exec_lock(ct::g_exec_mutex);
     if (hipMemsetAsync(l.hist, 0, (size_t)imgs * ct::kFsO * 2048 * sizeof(unsigned int), s) != hipSuccess) return (int)hipGetLastError();
     hipLaunchKernelGGL(ct::fsim_prep_kernel, gp, dim3(256), 0, s, a, b, h, w, f, hp, wp, l.lum, l.iq);
     CT_CHECK_LAUNCH();

@@ -62,35 +62,49 @@ def main(argv=None):
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     model = _instantiate(cfg["model"]).to(device).eval()
     if ckpt:
-        # Lightning checkpoints carry hyper-parameters / optimizer state next to "state_dict": not loadable with
-        # weights_only=True in general; a checkpoint path given on the command line is a trusted local file
+        # Lightning checkpoints carry hyper-parameters / optimizer state next to "state_dict"; weights_only=True refuses the
+        # ones that pickle arbitrary objects.  Falling back to the unsafe loader executes whatever the file pickles, so it
+        # happens only for that one error class and never silently; CT_TRUST_CKPT=0 forbids it.
+        import pickle
         try:
             state = torch.load(ckpt, map_location=device, weights_only=True)
-        except Exception:
+        except pickle.UnpicklingError as e:
+            if os.environ.get("CT_TRUST_CKPT", "1") == "0":
+                raise
+            print("warning: %s is not loadable with weights_only=True (%s); loading it as a TRUSTED pickle "
+                  "(set CT_TRUST_CKPT=0 to refuse)" % (ckpt, str(e).splitlines()[0][:120]), file=sys.stderr)
             state = torch.load(ckpt, map_location=device, weights_only=False)
         model.load_state_dict(state["state_dict"] if "state_dict" in state else state, strict=True)
     data_cfg = dict(cfg.get("data", {}))
     data_cfg["class_path"] = "utils.data.DataModule"
-    frames = _instantiate(data_cfg).test_frames()
-    mine = sh.frames_of_rank(len(frames), rank, world)
+    dm = _instantiate(data_cfg)
     from methods import METRICS, fsim, icid, psnr, ssim
     from utils.data import prefetch
-    rows = []
-    for f, sample in prefetch(frames, mine, device):       # pinned double-buffered uploads on a second stream
-        batch = {k: v.unsqueeze(0) for k, v in sample.items()}
-        if hasattr(model, "test_step"):
-            m = model.test_step(batch, f)
-            rows.append(torch.stack([m[k].reshape(()) for k in METRICS]))
-        else:                                   # CNN modules: forward(target, reference, inference=True)
-            corrected, _ = model(batch["target"], batch["reference"], inference=True)
-            corrected = corrected.clamp(0, 1)
-            rows.append(torch.stack([fn(corrected, batch["gt"]).reshape(()) for fn in (psnr, ssim, fsim, icid)]))
-    local = torch.stack(rows).double() if rows else torch.zeros((0, len(METRICS)), dtype=torch.float64, device=device)
-    table = sh.gather_frame_metrics(local, len(frames), rank, world)        # [n_frames, 4]: PSNR, SSIM, FSIM, iCID per frame
-    if rank == 0:
-        for i, name in enumerate(METRICS):
-            print("%s: %.4f" % (name, float(table[:, i].mean())), end="   " if i + 1 < len(METRICS) else "")
-        print("  (%d frames, %d GPU%s)" % (len(frames), world, "" if world == 1 else "s"))
+    # the reference's test_dataloader() returns [artificial, real-world] (utils/data.py:168-179) and Lightning logs each
+    # metric once per loader ("Test PSNR/dataloader_idx_1"); a single loader prints the bare names like Lightning does
+    loaders = dm.test_dataloader()
+    tables = []
+    for li, frames in enumerate(loaders):
+        mine = sh.frames_of_rank(len(frames), rank, world)
+        rows = []
+        for f, sample in prefetch(frames, mine, device):       # pinned double-buffered uploads on a second stream
+            batch = {k: v.unsqueeze(0) for k, v in sample.items()}
+            if hasattr(model, "test_step"):
+                m = model.test_step(batch, f)
+                rows.append(torch.stack([m[k].reshape(()) for k in METRICS]))
+            else:                                   # CNN modules: forward(target, reference, inference=True)
+                corrected, _ = model(batch["target"], batch["reference"], inference=True)
+                corrected = corrected.clamp(0, 1)
+                rows.append(torch.stack([fn(corrected, batch["gt"]).reshape(()) for fn in (psnr, ssim, fsim, icid)]))
+        local = torch.stack(rows).double() if rows else torch.zeros((0, len(METRICS)), dtype=torch.float64, device=device)
+        table = sh.gather_frame_metrics(local, len(frames), rank, world)        # [n_frames, 4]: PSNR, SSIM, FSIM, iCID per frame
+        tables.append(table)
+        if rank == 0:
+            suffix = "/dataloader_idx_%d" % li if len(loaders) > 1 else ""
+            for i, name in enumerate(METRICS):
+                print("%s%s: %.4f" % (name, suffix, float(table[:, i].mean())), end="   " if i + 1 < len(METRICS) else "")
+            print("  (%d frames, %d GPU%s)" % (len(frames), world, "" if world == 1 else "s"))
+    table = tables[0]
     if world > 1:
         dist.destroy_process_group()
     return table

@@ -161,6 +161,7 @@ def prefetch(dataset, indices, device):
     copy_stream = torch.cuda.Stream(device=device)
     staged = [None, None]
     pinned = [{}, {}]
+    slot_done = [None, None]                        # event of the last upload issued from each slot's pinned buffers
 
     def stage(slot, index):
         if hasattr(dataset, "host_frames"):
@@ -168,6 +169,10 @@ def prefetch(dataset, indices, device):
         else:
             host, extra = dataset[index], "float"
         dev = {}
+        # the pinned buffers of this slot are the SOURCE of the asynchronous copy issued two samples ago: the host must not
+        # refill them before that DMA has finished (the consumer stream waits on the event, the host so far did not)
+        if slot_done[slot] is not None:
+            slot_done[slot].synchronize()
         with torch.cuda.stream(copy_stream):
             for k, v in host.items():
                 buf = pinned[slot].get(k)
@@ -177,6 +182,7 @@ def prefetch(dataset, indices, device):
                 dev[k] = buf.to(device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(copy_stream)
+        slot_done[slot] = ev
         staged[slot] = (index, dev, extra, ev)
 
     stage(0, indices[0])
