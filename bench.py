@@ -73,6 +73,87 @@ def cpu_baseline(n_pairs=4):
                       "median %.3f s/pair; host has %d cores" % (n_pairs, med, os.cpu_count() or 0)}
 
 
+def video_stream(n_frames, dtype, device, rank, world, pool_size=16):
+    """BASELINE.json configs[4] on this rank's share of an n_frames 1080p stereo video (frame f -> rank f % world): every
+    frame triple (target, reference, ground truth) is UPLOADED from pinned host memory (the host buffers hand-over of the
+    drop-in boundary: PCIe is inside this measurement, unlike `value`), converted on the GPU if it is uint8, corrected by
+    methods.linear.color_transfer_between_images (one pair per call) and scored (PSNR fused into the apply sweep); the
+    [frames, 1] table is gathered with one collective at the end.  Uploads run on a copy stream, two frames ahead.
+    The host frames cycle through a pool of `pool_size` distinct pinned triples (decoding / generating 1000 distinct
+    frames on the host would measure the host: numpy's generator makes ~15 float frames/s)."""
+    import ct_hip
+    from utils import sharding as sh
+    np_dtype = np.uint8 if dtype == "u8" else np.float32
+    pool = []
+    for i in range(pool_size):
+        rng = np.random.default_rng(4321 + i)
+        trip = rng.integers(0, 256, (3, H, W, 3), dtype=np.uint8)
+        if dtype != "u8":
+            trip = trip.astype(np.float32) / np.float32(255)
+        pool.append(torch.from_numpy(np.ascontiguousarray(trip.astype(np_dtype))).pin_memory())
+    mine = sh.frames_of_rank(n_frames, rank, world)
+    n_local = len(mine)
+    copy_stream = torch.cuda.Stream(device=device)
+    main = torch.cuda.current_stream(device)
+    depth = 3
+    dev_raw = [torch.empty((3, H, W, 3), dtype=pool[0].dtype, device=device) for _ in range(depth)]
+    dev_f32 = torch.empty((3, H, W, 3), dtype=torch.float32, device=device)
+    uploaded = [torch.cuda.Event() for _ in range(depth)]
+    consumed = [torch.cuda.Event() for _ in range(depth)]
+    out = torch.empty((1, H, W, 3), dtype=torch.float32, device=device)
+    rec = torch.zeros((max(n_local, 1), 2), dtype=torch.float64, device=device)
+
+    def upload(i):
+        slot = i % depth
+        with torch.cuda.stream(copy_stream):
+            if i >= depth:
+                copy_stream.wait_event(consumed[slot])          # the kernels that read this slot's previous frame are done
+            dev_raw[slot].copy_(pool[mine[i] % pool_size], non_blocking=True)
+            uploaded[slot].record(copy_stream)
+
+    def process(i):
+        slot = i % depth
+        main.wait_event(uploaded[slot])
+        if dtype == "u8":
+            torch.mul(dev_raw[slot], 1.0 / 255.0, out=dev_f32)   # uint8 -> float32 in [0, 1] (utils/data.py:84,106,125: .float() / 255)
+            src = dev_f32
+        else:
+            src = dev_raw[slot]
+        ct_hip.reinhard_psnr(src[0:1], src[1:2], src[2:3], out=out, psnr_out=rec[i:i + 1])
+        consumed[slot].record(main)
+
+    # initialisation: code objects, clocks, the communicator
+    for i in range(min(depth, n_local)):
+        upload(i)
+    for i in range(min(depth, n_local)):
+        process(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(min(depth - 1, n_local)):
+        upload(i)
+    for i in range(n_local):
+        if i + depth - 1 < n_local:
+            upload(i + depth - 1)
+        process(i)
+    table = sh.gather_frame_metrics(rec[:n_local, 1:2], n_frames, rank, world)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    bytes_per_frame = 3 * H * W * 3 * pool[0].element_size()
+    return {"frames": n_frames, "host_dtype": dtype, "frames_per_s": n_frames / dt, "ms_per_frame_per_gpu": dt / max(n_local, 1) * 1e3,
+            "h2d_GB_per_s_per_gpu": bytes_per_frame * n_local / dt / 1e9, "h2d_bytes_per_frame": bytes_per_frame,
+            "pcie_gen5_x16_GB_per_s": 63.0, "mean_psnr": float(table[:, 0].mean()),
+            "note": "uploads (3 frames per stereo triple) on a copy stream two frames ahead, one pair per Reinhard call, PSNR fused, "
+                    "one gather; host frames from a pool of %d pinned triples" % pool_size}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,6 +162,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=16, help="stereopairs per step per GPU (one launch pair sweeps them all: the ~8 us a launch costs before it streams is paid once per step)")
     ap.add_argument("--metrics", default="psnr", help="per-frame metrics inside the timed region: psnr[,ssim,fsim,icid] or none")
     ap.add_argument("--init-seconds", type=float, default=0.25, help="clock / code-object initialisation before the warm-up steps")
+    ap.add_argument("--video", type=int, default=0, help="also stream this many 1080p frames from pinned host memory (configs[4]; 0 = the default "
+                    "1000 on single-GPU runs with the extras, off otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
@@ -275,7 +358,12 @@ def main():
             # configs[2]: DCMCS3DI forward, random init, 512x512.  The convolutions run float32 operands as three bf16
             # pieces with six bf16 MFMAs per product (float32-grade accuracy, csrc/conv_split.hip); rates are quoted in
             # algorithmic (float32) FLOPs against the FP32 matrix peak, and x6 against the dense bf16 peak.
-            extra["cnn_conv_arithmetic"] = "f32 as 3 bf16 pieces, 6 bf16 MFMAs per product, f32 accumulate (%s mode)" % ct_hip.conv_mode()
+            ws16 = ct_hip.conv_ws16() and ct_hip.conv_mode() == "split"
+            extra["cnn_conv_arithmetic"] = (
+                "float32 operands, float32 accumulate; ResB convs (3x3, cin 64): 2 fp16 pieces, 3 fp16 MFMAs per product, weights "
+                "stationary in registers (conv_ws); other convs / linears / attention: 3 bf16 pieces, 6 bf16 MFMAs per product"
+                if ws16 else "f32 as 3 bf16 pieces, 6 bf16 MFMAs per product, f32 accumulate (%s mode)" % ct_hip.conv_mode())
+            mfma_per_flop = 3.0 if ws16 else 6.0       # MFMA flops issued per algorithmic (float32) flop in the dominant convs
             from methods.dcmcs3di import DCMCS3DI
             torch.manual_seed(0)
             net = DCMCS3DI().to(device).eval()
@@ -284,7 +372,7 @@ def main():
             flop = 512 * 512 * (6591040 + 390 * 512)
             extra["dcmcs3di_512_pairs_per_s_f32"] = dc
             extra["dcmcs3di_512_tflops"] = flop * dc / 1e12
-            extra["dcmcs3di_512_frac_bf16_mfma_peak_x6"] = 6 * flop * dc / 2.5e15   # six bf16 MFMA flops per algorithmic flop
+            extra["dcmcs3di_512_frac_16bit_mfma_peak_issued"] = mfma_per_flop * flop * dc / 2.5e15   # MFMA flops issued per algorithmic flop
             # the size BASELINE.json's metric names: 1920x1080 (H*W*(6591040 + 390*W) FLOP/pair)
             l1080, r1080 = torch.rand(1, 3, H, W, device=device), torch.rand(1, 3, H, W, device=device)
             dc2 = rate(lambda: net(l1080, r1080, inference=True), n=3)
@@ -294,19 +382,23 @@ def main():
             # kernels run on: 6 bf16 MFMAs per float32 product in the convolutions and the q.k scores); `frac` = MFMA-busy from
             # the committed counter profile of the same forward (SQ_VALU_MFMA_BUSY_CYCLES over all kernels of the run, time
             # weighted, profiles/r02_dcmcs3di_1080p_mfma_pmc.json); achieved = issued bf16-MFMA-equivalent work, live.
-            pm = os.path.join(ROOT, "profiles", "r02_dcmcs3di_1080p_mfma_pmc.json")
+            pm = os.path.join(ROOT, "profiles", "r03_dcmcs3di_1080p_mfma_pmc.json")
             busy = json.load(open(pm)) if os.path.exists(pm) else {}
-            k33 = [v for k, v in busy.items() if "conv_split_kernel<3, 3" in k]
+            kdom = [v for k, v in busy.items() if "conv_ws_kernel" in k]
             roof_cnn = {"bound": "mfma", "workload": "dcmcs3di forward, random init, 1 pair of 1920x1080, float32 I/O",
-                        "dtype": "bf16 MFMA pipe (float32 operands as 3 bf16 pieces, 6 MFMAs per product), f32 accumulate",
-                        "achieved": 6 * flop2 * dc2 / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
-                        "frac_flops": 6 * flop2 * dc2 / 2.5e15,
+                        "dtype": "16-bit MFMA pipe (float32 operands as 2 fp16 pieces / 3 MFMAs per product in the ResB convs, 3 bf16 "
+                                 "pieces / 6 MFMAs elsewhere), f32 accumulate",
+                        "achieved": mfma_per_flop * flop2 * dc2 / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                        "frac_flops": mfma_per_flop * flop2 * dc2 / 2.5e15,
                         "frac": busy.get("_all_kernels", {}).get("mfma_busy_frac_time_weighted"),
+                        "frac_source": "profiles/r03_dcmcs3di_1080p_mfma_pmc.json (rocprofv3 --pmc pass of the same forward; not live)",
                         "frac_definition": "MFMA-busy: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), time-weighted over every "
-                                           "kernel of the forward (rocprofv3 --pmc, profiles/r02_dcmcs3di_1080p_mfma_pmc.json)",
-                        "dominant_kernel": "conv_split_kernel<3,3>",
-                        "dominant_kernel_mfma_busy": k33[0].get("mfma_busy_frac") if k33 else None,
-                        "pairs_per_s": dc2, "algorithmic_f32_tflops": flop2 * dc2 / 1e12}
+                                           "kernel of the forward",
+                        "dominant_kernel": "conv_ws_kernel<1, true>",
+                        "dominant_kernel_mfma_busy": kdom[0].get("mfma_busy_frac") if kdom else None,
+                        "pairs_per_s": dc2, "algorithmic_f32_tflops": flop2 * dc2 / 1e12,
+                        "note": "achieved = MFMA flops issued (3 per algorithmic flop in the fp16 two-piece convs); on real data the 16-bit "
+                                "matrix pipe of this chip is power limited near 1.1-1.3 PFLOP/s (DESIGN.md 4.4)"}
             del net, l1080, r1080
             # configs[3]: GMFlow matcher as DMSCT calls it (bidirectional + occlusion), random init, 540x960 -> 512x896
             from unimatch import GMFlow
@@ -317,7 +409,7 @@ def main():
             gr = rate(lambda: gm(a960, b960, inference_size=size, pred_bidir_flow=True, fwd_bwd_consistency_check=True), n=3)
             extra["gmflow_960x540_pairs_per_s_f32"] = gr
             extra["gmflow_960x540_tflops_f32_equivalent"] = 3.58357106688e12 * gr / 1e12
-            pm = os.path.join(ROOT, "profiles", "r02_gmflow_960x540_mfma_pmc.json")
+            pm = os.path.join(ROOT, "profiles", "r03_gmflow_960x540_mfma_pmc.json")
             if os.path.exists(pm):
                 extra["gmflow_960x540_mfma_busy_time_weighted"] = json.load(open(pm)).get("_all_kernels", {}).get("mfma_busy_frac_time_weighted")
             # configs[3] whole: DMSCT.forward (matcher + EfficientNet-B2 encoder on both views + fusion + U-Net decoder + head), random init
@@ -327,6 +419,16 @@ def main():
             extra["dmsct_960x540_pairs_per_s_f32"] = rate(lambda: dm(t960, r960), n=3)
             del dm
 
+    # configs[4] with the uploads inside the measurement: every rank takes part (frame f -> rank f % world)
+    n_video = args.video if args.video > 0 else (1000 if (world == 1 and not args.no_extra) else 0)
+    if n_video > 0:
+        del tgt, ref, gt, out
+        torch.cuda.empty_cache()
+        vid = {"u8": video_stream(n_video, "u8", device, rank, world)}
+        if world == 1:
+            vid["f32"] = video_stream(max(n_video // 4, 8), "f32", device, rank, world)
+        if rank == 0:
+            extra["video_stream"] = vid
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()

@@ -50,6 +50,37 @@ def assert_bitwise_vs_oracle(out, d, t, r, rot, bins):
     return o_out
 
 
+def assert_later_iterations_vs_reference(d, g, case, t, r, rot, bins):
+    """Iterations >= 1 against the REAL reference's integers (numpy's own per-pixel bin indices, counts, lo/hi): the working
+    image of those iterations differs from the reference's by its rounding (~1e-16 relative: numpy.linalg.solve against our
+    inverse x fma chain), so a bin index may differ only where the projected value sits on a bin edge to within 1e-12 of
+    the axis range, and then by exactly one bin; lo/hi agree to 1e-12 of the range; a histogram count moves by at most the
+    number of such pixels."""
+    _, o = oit.iterative_distribution_transfer(t, r, bins=bins, n_iter=rot.shape[0], rotations=rot, debug=True)
+    n_edge = 0
+    for it in range(1, rot.shape[0]):
+        want_idx, got_idx = g[case + "/binidx"][it].astype(np.int64), d["binidx"][0, it].astype(np.int64)
+        lohi_ref = g[case + "/lohi"][it]
+        lo, hi = d["par"][0, it, :, 0], d["par"][0, it, :, 1]
+        span = hi - lo
+        np.testing.assert_allclose(d["par"][0, it, :, 0:2], lohi_ref, rtol=0, atol=1e-12 * float(span.max()))
+        # the oracle's working image at the start of iteration `it` (bitwise the device's) and its projection
+        proj = oit.project(o["state"][it - 1], rot[it])                      # [3, n]
+        for ax in range(3):
+            bad = np.nonzero(want_idx[ax] != got_idx[ax])[0]
+            n_edge += bad.size
+            if bad.size == 0:
+                continue
+            assert np.abs(want_idx[ax][bad] - got_idx[ax][bad]).max() == 1, (it, ax)
+            pos = (proj[ax][bad] - lo[ax]) / span[ax] * bins                  # in units of bins
+            assert np.abs(pos - np.rint(pos)).max() <= 1e-12 * bins * 4, (it, ax, float(np.abs(pos - np.rint(pos)).max()))
+            assert np.abs(d["hist"][0, it, 0, ax].astype(np.int64) - g[case + "/hist0"][it][ax]).sum() <= 2 * bad.size
+        if not any((want_idx[ax] != got_idx[ax]).any() for ax in range(3)):
+            assert np.array_equal(d["hist"][0, it, 0].astype(np.int64), g[case + "/hist0"][it])
+    print("[idt %s] iterations >= 1: %d of %d bin indices on an edge (differ by one bin from the reference's)" % (
+        case, n_edge, 3 * (rot.shape[0] - 1) * want_idx.shape[-1] if rot.shape[0] > 1 else 0))
+
+
 @pytest.mark.parametrize("case,bins,n_iter", [("f64", 255, 4), ("f32", 255, 4), ("odd", 64, 2)])
 def test_idt_small_bitwise_and_vs_reference(golden_dir, hip, case, bins, n_iter):
     g = _g(golden_dir, "idt_small.npz")
@@ -61,6 +92,7 @@ def test_idt_small_bitwise_and_vs_reference(golden_dir, hip, case, bins, n_iter)
     assert np.array_equal(d["hist"][0, 0, 0].astype(np.int64), g[case + "/hist0"][0])
     assert np.array_equal(d["hist"][0, 0, 1].astype(np.int64), g[case + "/hist1"][0])
     assert np.array_equal(d["par"][0, 0, :, 0:2], g[case + "/lohi"][0])
+    assert_later_iterations_vs_reference(d, g, case, t, r, rot, bins)
     np.testing.assert_allclose(out, g[case + "/out"], rtol=0, atol=1e-9)
 
 

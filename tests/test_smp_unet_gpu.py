@@ -112,7 +112,8 @@ def test_encoder_decoder_head_vs_restatement(hip, n, h, w, conv_mode):
     assert e < 1e-5                                          # measured round 2: 4.1e-6
 
 
-def test_dmsct_forward_default_modules(hip, golden_dir):
+@pytest.mark.parametrize("h,w", [(200, 312), (540, 960)])      # 540 x 960 = BASELINE.json configs[3] at its full size
+def test_dmsct_forward_default_modules(hip, golden_dir, h, w):
     """DMSCT() as the reference constructs it (configs/dmsct.yaml): matcher + EfficientNet-B2 encoder + U-Net decoder + head
     on the device, against the float64 composition of the oracle pieces fed the device matcher's flow and mask."""
     from methods.dmsct import DMSCT
@@ -124,7 +125,7 @@ def test_dmsct_forward_default_modules(hip, golden_dir):
     hsd = o.random_state(o.head_param_shapes(), 17, torch.float64)
     hsd = {k: 0.2 * v for k, v in hsd.items()}                 # keep the residual inside [0, 1] for most pixels
     _load(model.encoder, esd); _load(model.decoder, dsd); _load(model.head, hsd)
-    h, w = 200, 312                                            # not a multiple of 16: replicate padding + crop are exercised
+    # 200 x 312 is not a multiple of 16 (replicate padding + crop are exercised); 540 pads to 544
     target, reference = torch.rand(1, 3, h, w, generator=G), torch.rand(1, 3, h, w, generator=G)
     out = model(target.cuda(), reference.cuda())
     assert out.shape == (1, 3, h, w) and torch.isfinite(out).all() and out.min() >= 0 and out.max() <= 1
@@ -137,4 +138,4 @@ def test_dmsct_forward_default_modules(hip, golden_dir):
     e = float((out.cpu().double() - want).abs().max())
     inside = float(((want > 0) & (want < 1)).double().mean())
     print("\n[dmsct default modules %dx%d] max-abs output error %.2e (%.0f%% of the pixels unclamped)" % (h, w, e, 100 * inside))
-    assert inside > 0.3 and e < 6e-5                         # measured round 2: 2.7e-5
+    assert inside > 0.3 and e < 6e-5                         # measured: 2.7e-5 (200 x 312, round 2)
