@@ -91,7 +91,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs a, int n_strip
 
 #ifdef CT_CONV_PROFILE
     // diagnostic build (make prof, tools/prof_conv_ws.py): s_memtime ticks per phase, per wave -> a.prof[block][wave][8]
-    // 0 X (MFMAs + partial sums), 1 barrier after X, 2 Y (reduce, requests, staging), 3 barrier after Y, 4 everything else
+    // 0 X (reduce of the previous row, MFMAs, partial sums), 1 the step's barrier, 2 Y (requests, row maximum, staging), 4 everything else
     unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt0;
 #define WS_STAMP0() asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pt0) :: "memory")
 #define WS_STAMP(i) do { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); pt[i] += t__ - pt0; pt0 = t__; } while (0)
@@ -397,33 +397,30 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs a, int n_strip
         // with the scale its maximum, noted one Y phase ago, asks for).  Loads are issued oldest-needed first (vmcnt is in order).
         auto phase_y = [&](int r, auto set_c) {
             constexpr int SET = decltype(set_c)::value;      // r % 3
-            fetch_skip(r + 1, rq[(SET + 1) % 3]);                  // consumed by reduce(r+1) inside X(r+2): three half steps from now at least
+            fetch_skip(r + 1, rq[(SET + 1) % 3]);                  // consumed by reduce(r+1) inside X(r+2): more than a step from now
             fetch_row(y0 + r + 4, qa[(SET + 2) % 3], qb[(SET + 2) % 3]);
             note_row_max((r + 1) & 1, y0 + r + 3, qa[(SET + 1) % 3], qb[(SET + 1) % 3]);   // F16: the row staged in Y(r+1)
             stage_row((r + 3) & (kWsRing - 1), y0 + r + 2, qa[SET], qb[SET], r & 1);   // the slot of input row y0+r-1 is free since X(r-1)
         };
-        // The two waves of a SIMD run the phases in opposite order, with a barrier after every half step: while one of them is
-        // in X (54 MFMAs) the other one does its Y -- with the same order in both, the matrix pipe sat idle through every Y
-        // (measured: full kernel = kernel without MFMAs + MFMA time).  Half step h: waves with mt == 0 run X(h/2) when h is
-        // even and Y(h/2) when it is odd; waves with mt == 1 the other way round.  Hazards: reduce(r-1) inside Y(r) runs at half
-        // steps 2r and 2r+1, after the last X(r-1) (2r-1); the row staged in Y(r) is read from X(r+1) on (>= 2r+2); its slot
-        // was last read in X(r-1); the partial-sum buffer r & 1 is rewritten in X(r+2) (>= 2r+4), after reduce(r) (<= 2r+3).
-        auto half_step = [&](int r, auto set_c, bool do_x) {
+        // The two waves of a SIMD run the phases of a step in opposite order -- while one of them is in X (27 or 54 MFMAs) the
+        // other one does its Y; with the same order in both, the matrix pipe sat idle through every Y (measured: full kernel =
+        // kernel without MFMAs + MFMA time) -- and ONE barrier ends the step.  Nothing inside a step depends on the other
+        // phase of the same step: X(r) reads ring slots r .. r+2 and the partial sums of step r-1 and writes the partial sums
+        // r & 1 (last read in step r-1); Y(r) writes ring slot r+3 (last read in step r-1), its exponent, and the row
+        // maximum (r+1) & 1, and reads the maxima r & 1 (written in step r-1).
+        auto step = [&](int r, auto set_c) {
             WS_STAMP(4);
-            if (do_x) { phase_x_full(r, set_c); WS_STAMP(0); }
-            else { phase_y(r, set_c); WS_STAMP(2); }
+            if (mt == 0) { phase_x_full(r, set_c); WS_STAMP(0); phase_y(r, set_c); WS_STAMP(2); }
+            else { phase_y(r, set_c); WS_STAMP(2); phase_x_full(r, set_c); WS_STAMP(0); }
             __syncthreads();
-            if (do_x) WS_STAMP(1); else WS_STAMP(3);
+            WS_STAMP(1);
         };
         const int steps = (rows + 2) / 3 * 3;
 #pragma unroll 1
         for (int r = 0; r < steps; r += 3) {
-            half_step(r, std::integral_constant<int, 0>(), mt == 0);
-            half_step(r, std::integral_constant<int, 0>(), mt == 1);
-            half_step(r + 1, std::integral_constant<int, 1>(), mt == 0);
-            half_step(r + 1, std::integral_constant<int, 1>(), mt == 1);
-            half_step(r + 2, std::integral_constant<int, 2>(), mt == 0);
-            half_step(r + 2, std::integral_constant<int, 2>(), mt == 1);
+            step(r, std::integral_constant<int, 0>());
+            step(r + 1, std::integral_constant<int, 1>());
+            step(r + 2, std::integral_constant<int, 2>());
         }
         reduce_row(steps - 1, rq[2]);                        // steps % 3 == 0: the skip row of the last step sits in set 2
         __syncthreads();      // the partial-sum tiles of the last rows are read before the next item overwrites them
