@@ -92,8 +92,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
         const int x0 = tx * kSpTW, y0 = ty * kSpTH, c0 = chunk * kSpKC;
         // two-source input: a 16-channel chunk lies entirely in one of the tensors (cin1 % 16 == 0)
-        const bool second = a.in2 && c0 >= a.cin1;
-        const float *in = second ? a.in2 + (size_t)n * a.in2_bstride + (size_t)(c0 - a.cin1) * plane
+        const bool third = a.in3 && c0 >= a.cin2;
+        const bool second = !third && a.in2 && c0 >= a.cin1;
+        const float *in = third ? a.in3 + (size_t)n * a.in3_bstride + (size_t)(c0 - a.cin2) * plane
+                        : second ? a.in2 + (size_t)n * a.in2_bstride + (size_t)(c0 - a.cin1) * plane
                                  : a.in + (size_t)n * a.in_bstride + (size_t)c0 * plane;
         if (unit) {
             const int gy = y0 + u_row - PADY, gx = x0 + 4 * u_g;
@@ -418,6 +420,7 @@ static int launch_split(const ConvArgs &a, int N, hipStream_t s) {
 int conv_split(const ConvArgs &a, int N, int kh, int kw, bool gen, hipStream_t s) {
     const bool vec = (a.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.in) & 15) == 0) && (a.in_bstride % 4 == 0) &&
                      (!a.in2 || (((reinterpret_cast<uintptr_t>(a.in2) & 15) == 0) && (a.in2_bstride % 4 == 0) && (a.cin1 % 16 == 0))) &&
+                     (!a.in3 || (((reinterpret_cast<uintptr_t>(a.in3) & 15) == 0) && (a.in3_bstride % 4 == 0) && (a.cin2 % 16 == 0))) &&
                      ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0) && (a.out_bstride % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(a.wp) & 15) == 0) &&
                      (!a.residual || (((reinterpret_cast<uintptr_t>(a.residual) & 15) == 0) && (a.res_bstride % 4 == 0)));
@@ -442,14 +445,17 @@ int conv_split(const ConvArgs &a, int N, int kh, int kw, bool gen, hipStream_t s
 
 extern "C" {
 
-int ct_conv2d_split_f32(const float *in, const float *in2, int cin1, const void *wp_split, const float *bias, const float *residual,
-                        float *out, int n, int cin, int cout, int h, int w, int kh, int kw, long long in_bstride,
-                        long long in2_bstride, long long out_bstride, long long res_bstride, int act, int clamp, void *stream) {
+int ct_conv2d_split_f32(const float *in, const float *in2, int cin1, const float *in3, int cin2, const void *wp_split, const float *bias,
+                        const float *residual, float *out, int n, int cin, int cout, int h, int w, int kh, int kw, long long in_bstride,
+                        long long in2_bstride, long long in3_bstride, long long out_bstride, long long res_bstride, int act, int clamp,
+                        void *stream) {
     if (!in || !wp_split || !bias || !out || n < 0 || cin < 1 || cout < 1 || h < 0 || w < 0 || act < 0 || act > 5) return CT_E_BADARG;
     if (in2 && (cin1 < 16 || cin1 >= cin || (cin1 % 16))) return CT_E_BADARG;
+    if (in3 && (!in2 || cin2 <= cin1 || cin2 >= cin || (cin2 % 16))) return CT_E_BADARG;
     if (n == 0 || h == 0 || w == 0) return CT_OK;
     ct::ConvArgs a;
     a.in = in; a.in2 = in2; a.cin1 = in2 ? cin1 : cin; a.in2_bstride = in2_bstride;
+    a.in3 = in3; a.cin2 = in3 ? cin2 : cin; a.in3_bstride = in3_bstride;
     a.wp = reinterpret_cast<const float *>(wp_split); a.bias = bias; a.residual = residual; a.out = out;
     a.cin = cin; a.cout = cout; a.H = h; a.W = w;
     a.in_bstride = in_bstride; a.out_bstride = out_bstride; a.res_bstride = res_bstride;

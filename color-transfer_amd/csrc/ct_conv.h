@@ -20,6 +20,9 @@ struct ConvArgs {
     int groups;  // output-channel groups of MT*32 (weights packed group-major); 1 for cout <= 64
     unsigned long long *prof;   // diagnostic builds only (CT_CONV_PROFILE); NULL otherwise
     int n_images = 0;           // conv_ws only (set by its launcher)
+    const float *in3 = nullptr;  // split kernel only: channels >= cin2 come from this tensor (a third torch.cat operand); cin2 % 16 == 0
+    int cin2 = 0;
+    long long in3_bstride = 0;
     int f16 = 0;                // conv_ws only: 1 = two fp16 pieces (weights scaled by 2^w_exp), 0 = three bf16 pieces
     int w_exp = 0;
 };

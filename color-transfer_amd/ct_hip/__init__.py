@@ -522,8 +522,8 @@ SIGNATURES.update({
     "ct_conv2d_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ll, _c_ll,
                                _c_ll, _c_int, _c_int, _c_p]),
     "ct_pam_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
-    "ct_conv2d_split_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                                     _c_int, _c_ll, _c_ll, _c_ll, _c_ll, _c_int, _c_int, _c_p]),
+    "ct_conv2d_split_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                     _c_int, _c_int, _c_ll, _c_ll, _c_ll, _c_ll, _c_ll, _c_int, _c_int, _c_p]),
     "ct_pam_attend_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "ct_pam_valid_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_sz, _c_p]),
 })
@@ -622,19 +622,21 @@ def _split_ok(x, out, residual, kh, kw, stride, ph, pw):
     return True
 
 
-def _conv_split(x, split, cout, kh, kw, act, residual, clamp, out, x2=None):
+def _conv_split(x, split, cout, kh, kw, act, residual, clamp, out, x2=None, x3=None):
     ws, b64 = split[0], split[1]
     n, cin1, h, w = x.shape
-    cin = cin1 + (x2.shape[1] if x2 is not None else 0)
+    cin2 = cin1 + (x2.shape[1] if x2 is not None else 0)
+    cin = cin2 + (x3.shape[1] if x3 is not None else 0)
     rs = _nchw_bstride(residual) if residual is not None else 0
     if x2 is None and _ws16_ok(x, split, kh, kw):
         w16, w_exp = split[2]
         check(lib().ct_conv3x3_ws16_f32(_ptr(x), _ptr(w16), int(w_exp), _ptr(b64), _opt(residual), _ptr(out), n, cin, cout, h, w,
                                         _nchw_bstride(x), _nchw_bstride(out), rs, int(act), int(bool(clamp)), _stream()))
         return out
-    check(lib().ct_conv2d_split_f32(_ptr(x), _opt(x2), cin1, _ptr(ws), _ptr(b64), _opt(residual), _ptr(out), n, cin, cout, h, w,
-                                    kh, kw, _nchw_bstride(x), _nchw_bstride(x2) if x2 is not None else 0, _nchw_bstride(out),
-                                    rs, int(act), int(bool(clamp)), _stream()))
+    check(lib().ct_conv2d_split_f32(_ptr(x), _opt(x2), cin1, _opt(x3), cin2, _ptr(ws), _ptr(b64), _opt(residual), _ptr(out), n, cin,
+                                    cout, h, w, kh, kw, _nchw_bstride(x), _nchw_bstride(x2) if x2 is not None else 0,
+                                    _nchw_bstride(x3) if x3 is not None else 0, _nchw_bstride(out), rs, int(act), int(bool(clamp)),
+                                    _stream()))
     return out
 
 
@@ -662,8 +664,21 @@ def _nchw_bstride(t):
     return t.stride(0)
 
 
-def conv2d(x, wp, bias, cout, ksize, act=0, residual=None, clamp=False, out=None):
-    """Conv2d(ksize, padding=ksize//2) + bias [+ LeakyReLU(0.01)] [+ residual] [clamp 0..1], float32 NCHW."""
+def conv2d(x, wp, bias, cout, ksize, act=0, residual=None, clamp=False, out=None, x2=None, x3=None):
+    """Conv2d(ksize, padding=ksize//2) + bias [+ LeakyReLU(0.01)] [+ residual] [clamp 0..1], float32 NCHW.
+    x2 / x3: further input tensors whose channels follow x's -- torch.cat([x, x2, x3], 1) without the copy when the split kernel
+    takes the convolution (channel counts of x and x + x2 multiples of 16); otherwise the concatenation is materialised here."""
+    if x2 is not None:
+        split = getattr(wp, "_ct_split", None)
+        c1, c2 = x.shape[1], x.shape[1] + x2.shape[1]
+        ok = (split is not None and c1 % 16 == 0 and (x3 is None or c2 % 16 == 0) and
+              all(t is None or (t.is_cuda and t.dtype == torch.float32 and t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and
+                                t[0].is_contiguous()) for t in (x2, x3)))
+        if out is None:
+            out = torch.empty((x.shape[0], cout, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
+        if ok and _split_ok(x, out, residual, ksize, ksize, 1, ksize // 2, ksize // 2):
+            return _conv_split(x, split, cout, ksize, ksize, act, residual, clamp, out, x2=x2, x3=x3)
+        x = torch.cat([t for t in (x, x2, x3) if t is not None], dim=1)
     if x.is_cuda:
         _check_device(x)
     if not x.is_cuda or x.dtype != torch.float32:

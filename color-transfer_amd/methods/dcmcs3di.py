@@ -2,10 +2,13 @@
 for the FORWARD pass of the reference's methods/dcmcs3di.py:29-66.
 
 Same constructor arguments, parameter names/shapes (reference checkpoints `load_state_dict`
-strictly) and `forward(left, right, inference)` return structure.  Every convolution runs in
-ct_conv2d_f32 (LDS-tiled implicit GEMM on exact-f32 MFMA), the parallax attention in
-ct_pam_attend_f32 / ct_pam_valid_f32; torch only allocates tensors and concatenates.  Training
-(`step`, losses, logging: dcmcs3di.py:68-147) is out of scope.  No CPU fallback.
+strictly) and `forward(left, right, inference)` return structure.  The ResB convolutions run in
+ct_conv3x3_ws16_f32 (weights stationary in registers, two fp16 pieces per float32 operand), the
+other convolutions in ct_conv2d_split_f32 (three bf16 pieces) -- or all of them in ct_conv2d_f32
+(exact-f32 MFMA) in `exact` mode; the parallax attention in the streaming kernels behind
+ct_hip.pam_streaming (ct_pam_attend_f32 / ct_pam_valid_f32 when the [B,H,W,W] maps are wanted); torch
+only allocates tensors.  Training (`step`, losses, logging: dcmcs3di.py:68-147) is out of scope.
+No CPU fallback.
 """
 import torch
 
@@ -69,9 +72,11 @@ class DCMCS3DI(torch.nn.Module):
             att_r2l = att_l2r = None
             fea_warped, warped_rgb, valid_left, colsum_left = ct_hip.pam_streaming(
                 q[:B].contiguous(), k[B:].contiguous(), v, right, q[B:].contiguous(), k[:B].contiguous())
-        x = torch.cat([fea_left, fea_warped, valid_left], dim=1)           # dcmcs3di.py:59 (bool -> float)
+        # dcmcs3di.py:59,47: transfer[0] (1x1, 129 -> 64) reads cat([fea_left, fea_warped, valid_left]) straight from its
+        # three tensors (a three-source K loop in ct_conv2d_split_f32; the 129-channel tensor is never built)
+        x = conv_forward(self.transfer[0], fea_left, x2=fea_warped, x3=valid_left)
         n_t = len(self.transfer)
-        for i in range(n_t - 1):
+        for i in range(1, n_t - 1):
             m = self.transfer[i]
             x = resb_forward(m, x) if isinstance(m, ResB) else conv_forward(m, x)
         pre_clamp = conv_forward(self.transfer[n_t - 1], x)

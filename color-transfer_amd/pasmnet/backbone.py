@@ -23,10 +23,12 @@ def packed_weights(conv):
     return cached[1]
 
 
-def conv_forward(conv, x, act=0, residual=None, clamp=False, out=None):
-    """one Conv2d (3x3 / 1x1, stride 1, "same") with its epilogue fused: bias, LeakyReLU (act=1), skip tensor, clamp"""
+def conv_forward(conv, x, act=0, residual=None, clamp=False, out=None, x2=None, x3=None):
+    """one Conv2d (3x3 / 1x1, stride 1, "same") with its epilogue fused: bias, LeakyReLU (act=1), skip tensor, clamp; x2 / x3:
+    tensors whose channels follow x's (the conv reads torch.cat([x, x2, x3], 1) without the concatenation being built)"""
     wp, bias = packed_weights(conv)
-    return ct_hip.conv2d(x, wp, bias, conv.out_channels, conv.kernel_size[0], act=act, residual=residual, clamp=clamp, out=out)
+    return ct_hip.conv2d(x, wp, bias, conv.out_channels, conv.kernel_size[0], act=act, residual=residual, clamp=clamp, out=out,
+                         x2=x2, x3=x3)
 
 
 def resb_forward(block, x, out=None):

@@ -236,10 +236,12 @@ int ct_conv2d_f32(const float *in, const float *wp, const float *bias, const flo
  * wp_split: bf16 bit patterns [ceil(cout/64)][ceil(cin/16)][kh*kw][piece hi,mid,lo][m][k-half][cout%32][8 channels];
  * bias: zero padded to 64*ceil(cout/64).  act: 0 none, 1 LeakyReLU(0.01), 2 ReLU, 3 sigmoid, 4 tanh, 5 swish.
  * in2 != NULL: input channels [cin1, cin) come from in2 (cin1 % 16 == 0) -- torch.cat([a, b], dim=1) without the copy
- * (reg_refine.py:43,72,75: the GRU's hx / [r*h, x] and the motion encoder's [cor, flo]).                            */
-int ct_conv2d_split_f32(const float *in, const float *in2, int cin1, const void *wp_split, const float *bias,
-                        const float *residual, float *out, int n, int cin, int cout, int h, int w, int kh,
-                        int kw, long long in_bstride, long long in2_bstride, long long out_bstride,
+ * (reg_refine.py:43,72,75: the GRU's hx / [r*h, x] and the motion encoder's [cor, flo]).
+ * in3 != NULL (needs in2): channels [cin2, cin) come from in3 (cin2 % 16 == 0, cin1 < cin2 < cin): DCMCS3DI's
+ * transfer[0] reads cat([fea_left, fea_warped, valid_left]) (methods/dcmcs3di.py:59,47) from its three tensors.            */
+int ct_conv2d_split_f32(const float *in, const float *in2, int cin1, const float *in3, int cin2, const void *wp_split,
+                        const float *bias, const float *residual, float *out, int n, int cin, int cout, int h, int w, int kh,
+                        int kw, long long in_bstride, long long in2_bstride, long long in3_bstride, long long out_bstride,
                         long long res_bstride, int act, int clamp, void *stream);
 
 /* The ResB convolutions (3x3, stride 1, padding 1, 32 < cin <= 64; reference pasmnet/backbone.py:8-15, unimatch/backbone.py
