@@ -135,7 +135,13 @@ def test_dmsct_forward_default_modules(hip, golden_dir, h, w):
     fr = o.encoder_forward(esd, F.pad(reference.double(), pad, mode="replicate"))
     fused = og.dmsct_fuse_features(m["flow"].cpu().double(), m["fwd_occ"].cpu().double(), ft, fr, pad)
     want = torch.clamp(target.double() + o.head_forward(hsd, o.decoder_forward(dsd, *fused))[:, :, :h, :w], 0, 1)
+    # the same glue lines in float32, as the reference evaluates them (flow_warp's sampling coordinates): with the huge, rough
+    # flow fields of a random-weight matcher at full size their distance from float64 is the floor of any float32 pipeline
+    fused32 = og.dmsct_fuse_features(m["flow"].cpu(), m["fwd_occ"].cpu(), [f.float() for f in ft], [f.float() for f in fr], pad)
+    want32 = torch.clamp(target.double() + o.head_forward(hsd, o.decoder_forward(dsd, *[f.double() for f in fused32]))[:, :, :h, :w], 0, 1)
+    floor = float((want32 - want).abs().max())
     e = float((out.cpu().double() - want).abs().max())
     inside = float(((want > 0) & (want < 1)).double().mean())
-    print("\n[dmsct default modules %dx%d] max-abs output error %.2e (%.0f%% of the pixels unclamped)" % (h, w, e, 100 * inside))
-    assert inside > 0.3 and e < 6e-5                         # measured: 2.7e-5 (200 x 312, round 2)
+    print("\n[dmsct default modules %dx%d] max-abs output error %.2e (float32 glue of the reference vs float64: %.2e; %.0f%% of the "
+          "pixels unclamped)" % (h, w, e, floor, 100 * inside))
+    assert inside > 0.3 and e < max(6e-5, 2 * floor)         # measured: 2.7e-5 (200 x 312, round 2)
