@@ -1,0 +1,94 @@
+"""GPU parity of the weight-stationary 3x3 convolution (csrc/conv_ws.hip) in its fp16 two-piece form (ct_conv3x3_ws16_f32) and
+its bf16 three-piece form, against float64 torch convolutions: every geometry branch (partial strips, row segments that are
+not multiples of three, fewer than four input chunks, odd channel counts, several output groups), every epilogue, and the
+per-row power-of-two scaling (rows of very different magnitude, zero rows, scale changes between neighbouring rows)."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+import torch.nn.functional as F   # noqa: E402
+
+G = torch.Generator().manual_seed(11)
+
+
+def rnd(*shape):
+    return torch.randn(*shape, generator=G)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import ct_hip
+    ct_hip.lib()
+    return ct_hip
+
+
+CASES = [(2, 64, 64, 24, 64), (1, 64, 32, 9, 36), (1, 48, 64, 50, 100), (1, 33, 7, 5, 8), (1, 64, 130, 40, 64), (3, 64, 64, 17, 32)]
+
+
+@pytest.mark.parametrize("ws16", [True, False])
+@pytest.mark.parametrize("cfg", CASES)
+def test_conv_ws_vs_float64(hip, cfg, ws16):
+    n, cin, cout, h, w = cfg
+    x, wt, b = rnd(n, cin, h, w) * 3, rnd(cout, cin, 3, 3) / (cin * 9) ** 0.5, rnd(cout)
+    res = rnd(n, cout, h, w)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    wp, bp = hip.pack_conv_weight(wt.cuda(), b.cuda())
+    assert wp._ct_split[2] is not None                      # the fp16 image travels with the packing
+    tol = 2e-6 * max(1.0, ref.abs().max().item())
+    hip.set_conv_ws16(ws16)
+    try:
+        for act, fn in ((0, lambda t: t), (1, lambda t: F.leaky_relu(t, 0.01))):
+            out = hip.conv2d(x.cuda(), wp, bp, cout, 3, act=act)
+            assert (out.double().cpu() - fn(ref)).abs().max().item() < tol, (cfg, ws16, act)
+        out = hip.conv2d(x.cuda(), wp, bp, cout, 3, act=1, residual=res.cuda(), clamp=True)
+        assert (out.double().cpu() - (F.leaky_relu(ref, 0.01) + res.double()).clamp(0, 1)).abs().max().item() < tol
+        # the generic activations go through ct_conv2d_split_f32 / gconv2d's path (ReLU, sigmoid)
+        wpg, bpg = hip.pack_gconv_weight(wt.cuda(), b.cuda())
+        for act, fn in ((2, torch.relu), (3, torch.sigmoid)):
+            out = hip.gconv2d(x.cuda(), wpg, bpg, cout, 3, 1, 1, act=act)
+            assert (out.double().cpu() - fn(ref)).abs().max().item() < tol, (cfg, ws16, act)
+        # non-contiguous batch views (the two views of a stereo pair live in one tensor)
+        if n >= 2:
+            big = rnd(n + 1, cin, h, w)
+            out = hip.conv2d(big.cuda()[1:], wp, bp, cout, 3)
+            want = F.conv2d(big[1:].double(), wt.double(), b.double(), padding=1)
+            assert (out.double().cpu() - want).abs().max().item() < 2e-6 * max(1.0, want.abs().max().item())
+    finally:
+        hip.set_conv_ws16(True)
+
+
+def test_conv_ws16_row_scales(hip):
+    """Per-row power-of-two scales: rows whose magnitudes differ by 10^10 inside one image, zero rows, a scale change between
+    every pair of neighbouring rows; the error stays at float32-summation level RELATIVE TO EACH OUTPUT ROW's own magnitude."""
+    n, cin, cout, h, w = 1, 64, 64, 36, 64
+    x = rnd(n, cin, h, w)
+    scale = torch.ones(h)
+    scale[:6] = 1e-6
+    scale[6:12] = 3e4
+    scale[12:15] = 0.0
+    scale[15:] = torch.tensor([2.0 ** ((i * 7) % 11 - 5) for i in range(h - 15)])      # a different exponent on every row
+    x = x * scale.view(1, 1, h, 1)
+    wt, b = rnd(cout, cin, 3, 3) / 24, torch.zeros(cout)
+    ref = F.conv2d(x.double(), wt.double(), None, padding=1)
+    wp, bp = hip.pack_conv_weight(wt.cuda(), b.cuda())
+    out = hip.conv2d(x.cuda(), wp, bp, cout, 3).double().cpu()
+    # an output row sums three input rows: its error scales with the largest of them
+    mag = torch.stack([F.pad(scale, (1, 1))[i:i + h] for i in range(3)]).max(0).values
+    err = (out - ref).abs().amax(dim=(0, 1, 3))
+    assert (err <= 4e-6 * mag + 1e-30).all(), (err / (mag + 1e-30)).max().item()
+    assert (out[:, :, 13] == 0).all()                       # a row whose three input rows are zero is exactly zero
+    # power-of-two scaling of the input is exact: the row scales absorb it
+    out2 = hip.conv2d((x * 1024.0).cuda(), wp, bp, cout, 3).double().cpu()
+    assert torch.equal(out * 1024.0, out2)
+
+
+def test_conv_ws16_entry_argument_checks(hip):
+    import ctypes
+    lib = hip.lib()
+    x = torch.zeros(1, 64, 8, 32, device="cuda")
+    null = ctypes.c_void_p(0)
+    p = ctypes.c_void_p(x.data_ptr())
+    assert lib.ct_conv3x3_ws16_f32(null, p, 0, p, null, p, 1, 64, 64, 8, 32, 0, 0, 0, 0, 0, null) == -1        # null input
+    assert lib.ct_conv3x3_ws16_f32(p, p, 0, p, null, p, 1, 32, 64, 8, 32, 0, 0, 0, 0, 0, null) == -1           # cin <= 32
+    assert lib.ct_conv3x3_ws16_f32(p, p, 0, p, null, p, 1, 64, 64, 8, 30, 0, 0, 0, 0, 0, null) == -3           # W % 4
+    assert lib.ct_conv3x3_ws16_f32(p, p, 0, p, null, p, 0, 64, 64, 8, 32, 0, 0, 0, 0, 0, null) == 0            # empty batch
