@@ -11,7 +11,8 @@
 //
 // All arithmetic is float64 (the reference's `img_arr_col` is the float64 IDT output; a float32 target is promoted here
 // where the reference resizes it in float32 -- a 1e-7-level difference, see tests).  HWC layout, one thread per pixel;
-// every launch is a plain streaming / 5-point stencil sweep (HBM bound; 244 launches for a 1080p frame).
+// the relaxation runs k = 8 sweeps per launch on LDS-resident tiles with a recomputed halo (rg_sweepk_kernel: 31 sweep launches
+// for a 1080p frame instead of 244, bitwise the same result); the resizes are plain streaming kernels.
 #include "ct_common.h"
 
 namespace ct {
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(kBlock) void rg_bilinear_kernel(const double *__res
     }
 }
 
+
 // iterative.py:91-98: gradient magnitude of the original image -> psi, phi  (wt[i] = {psi, phi})
 __global__ __launch_bounds__(kBlock) void rg_weights_kernel(const double *__restrict__ in, double2 *__restrict__ wt, int H, int W, double phi_scale) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -109,12 +111,112 @@ __global__ __launch_bounds__(kBlock) void rg_sweep_kernel(const double *__restri
     const double phi1 = (wt[iR].y + phi) / 2, phi2 = (wt[iD].y + phi) / 2, phi3 = (wt[iL].y + phi) / 2, phi4 = (wt[iU].y + phi) / 2;
     const double den = psi + phi1 + phi2 + phi3 + phi4;
     const double eps = 1e-6, rho = 1 / 5.0;
+    // (num / (den + eps)) * (1 - rho) of the reference as num * scale: the quotient does not depend on the channel or the sweep
+    // (one float64 division per pixel instead of three per sweep; the last bit may differ from the reference's order, the
+    // relaxation is contractive: 1e-15 on the result, tests/test_regrain.py asserts 1e-9)
+    const double scale = (1 - rho) / (den + eps);
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         const double x = in[i * 3 + ch];
         const double num = psi * col[i * 3 + ch] + phi1 * (prev[iR * 3 + ch] - in[iR * 3 + ch] + x) + phi2 * (prev[iD * 3 + ch] - in[iD * 3 + ch] + x) +
                            phi3 * (prev[iL * 3 + ch] - in[iL * 3 + ch] + x) + phi4 * (prev[iU * 3 + ch] - in[iU * 3 + ch] + x);
-        next[i * 3 + ch] = num / (den + eps) * (1 - rho) + rho * prev[i * 3 + ch];
+        next[i * 3 + ch] = num * scale + rho * prev[i * 3 + ch];
+    }
+}
+
+// K sweeps of rg_sweep_kernel in ONE launch (temporal blocking with a recomputed halo): a workgroup owns a th x tw tile of
+// the level, loads it with a halo of k pixels and runs k Jacobi sweeps on the WHOLE region, synchronising with
+// barriers instead of launch boundaries.  Region pixels whose neighbours lie outside the region use the nearest region pixel
+// instead: that garbage travels inward one pixel per sweep and after k sweeps has eaten exactly the halo; the tile itself is
+// what rg_sweep_kernel would have produced, operation for operation (the per-pixel arithmetic below is the same code).
+// Neighbours outside the IMAGE are the pixel itself in both kernels (min / max clamping, iterative.py:100-104).
+// A 1080p frame: 244 sweep launches become 31 (nbits 4, 16, 32, 64, 64, 64 with k = 8).
+constexpr int kRgKMax = 8;
+constexpr int kRgMaxRegion = 1536;                      // (16 + 2 k) x (32 + 2 k) at k = 8
+constexpr int kRgPxPerThread = kRgMaxRegion / kBlock;   // 6
+
+// LDS holds ONE quantity per pixel and channel, d = iterate - in (what a neighbour needs: the formula reads prev[k] - in[k]),
+// twice for the ping-pong; everything else a pixel needs in every sweep lives in the registers of the thread that owns it:
+// in, the current iterate, psi * col, the four neighbour weights and the hoisted scale.
+__global__ __launch_bounds__(kBlock) void rg_sweepk_kernel(const double *__restrict__ prev, const double *__restrict__ in, const double *__restrict__ col,
+                                                          const double2 *__restrict__ wt, double *__restrict__ next, int H, int W, int th, int tw,
+                                                          int k, int tiles_x) {
+    extern __shared__ double lds[];
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int y0 = ty * th, x0 = tx * tw;
+    // region = tile + halo, clipped to the image
+    const int ry0 = max(y0 - k, 0), ry1 = min(y0 + th + k, H), rx0 = max(x0 - k, 0), rx1 = min(x0 + tw + k, W);
+    const int rh = ry1 - ry0, rw = rx1 - rx0, rn = rh * rw;
+    double *dA = lds, *dB = lds + 3 * kRgMaxRegion, *phiL = lds + 6 * kRgMaxRegion;
+    double inr[kRgPxPerThread][3], cur[kRgPxPerThread][3], pc[kRgPxPerThread][3], ph[kRgPxPerThread][4], sc[kRgPxPerThread];
+    int nb[kRgPxPerThread][4];
+#pragma unroll
+    for (int j = 0; j < kRgPxPerThread; ++j) {
+        const int p = threadIdx.x + j * kBlock;
+        if (p < rn) {
+            const int r = p / rw, c = p - r * rw;
+            const size_t g = (size_t)(ry0 + r) * W + (rx0 + c);
+            const double2 w0 = wt[g];
+            ph[j][0] = w0.x;                                   // psi for now
+            phiL[p] = w0.y;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                inr[j][ch] = in[g * 3 + ch]; cur[j][ch] = prev[g * 3 + ch]; pc[j][ch] = col[g * 3 + ch];
+                dA[p * 3 + ch] = cur[j][ch] - inr[j][ch];
+            }
+            // image clamping == region clamping wherever the region edge is an image edge; elsewhere: halo garbage
+            nb[j][0] = r * rw + min(c + 1, rw - 1); nb[j][1] = min(r + 1, rh - 1) * rw + c;
+            nb[j][2] = r * rw + max(c - 1, 0);      nb[j][3] = max(r - 1, 0) * rw + c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kRgPxPerThread; ++j) {
+        const int p = threadIdx.x + j * kBlock;
+        if (p < rn) {
+            const double psi = ph[j][0], phi = phiL[p];
+            const double phi1 = (phiL[nb[j][0]] + phi) / 2, phi2 = (phiL[nb[j][1]] + phi) / 2, phi3 = (phiL[nb[j][2]] + phi) / 2,
+                         phi4 = (phiL[nb[j][3]] + phi) / 2;
+            const double den = psi + phi1 + phi2 + phi3 + phi4;
+            const double eps = 1e-6, rho = 1 / 5.0;
+            sc[j] = (1 - rho) / (den + eps);
+            ph[j][0] = phi1; ph[j][1] = phi2; ph[j][2] = phi3; ph[j][3] = phi4;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) pc[j][ch] = psi * pc[j][ch];
+        }
+    }
+    double *dc = dA, *dn = dB;
+    for (int sweep = 0; sweep < k; ++sweep) {
+#pragma unroll
+        for (int j = 0; j < kRgPxPerThread; ++j) {
+            const int p = threadIdx.x + j * kBlock;
+            if (p < rn) {
+                const double rho = 1 / 5.0;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const double x = inr[j][ch];
+                    const double num = pc[j][ch] + ph[j][0] * (dc[nb[j][0] * 3 + ch] + x) + ph[j][1] * (dc[nb[j][1] * 3 + ch] + x) +
+                                       ph[j][2] * (dc[nb[j][2] * 3 + ch] + x) + ph[j][3] * (dc[nb[j][3] * 3 + ch] + x);
+                    cur[j][ch] = num * sc[j] + rho * cur[j][ch];
+                    dn[p * 3 + ch] = cur[j][ch] - x;
+                }
+            }
+        }
+        __syncthreads();
+        double *t = dc; dc = dn; dn = t;
+    }
+    // the tile (the part of the region that lies k pixels away from every non-image edge of it)
+#pragma unroll
+    for (int j = 0; j < kRgPxPerThread; ++j) {
+        const int p = threadIdx.x + j * kBlock;
+        if (p < rn) {
+            const int r = p / rw, c = p - r * rw, gy = ry0 + r, gx = rx0 + c;
+            if (gy >= y0 && gy < min(y0 + th, H) && gx >= x0 && gx < min(x0 + tw, W)) {
+                const size_t g = (size_t)gy * W + gx;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) next[g * 3 + ch] = cur[j][ch];
+            }
+        }
     }
 }
 
@@ -136,19 +238,29 @@ static inline dim3 rg_grid(int64_t n) { return dim3((unsigned)((n + kBlock - 1) 
 // skimage.transform.resize(src [hi][wi][3] -> dst [ho][wo][3]); tmp: two [hi][wi][3] buffers (down-scaling only)
 static int rg_resize(const double *src, int hi, int wi, double *dst, int ho, int wo, double *tmp0, double *tmp1, hipStream_t s) {
     const double fr = (double)hi / (double)ho, fc = (double)wi / (double)wo;
-    const double *cur = src;
-    double *bufs[2] = {tmp0, tmp1};
-    int nb = 0;
+    int radius[2] = {0, 0};
+    double wts[2][3] = {{1.0, 0.0, 0.0}, {1.0, 0.0, 0.0}};
+    bool filtered[2] = {false, false};
     for (int axis = 0; axis < 2; ++axis) {
         const double f = axis == 0 ? fr : fc;
         const double sigma = f > 1.0 ? (f - 1.0) / 2.0 : 0.0;
         if (!(sigma > 1e-15)) continue;                               // scipy skips such axes
-        const int radius = (int)(4.0 * sigma + 0.5);
-        if (radius > 2) return CT_E_BADARG;                           // halving pyramids never get here
-        double w[3] = {1.0, 0.0, 0.0}, sum = 0.0;
-        for (int k = -radius; k <= radius; ++k) sum += exp(-0.5 / (sigma * sigma) * (double)(k * k));
-        for (int k = 0; k <= radius; ++k) w[k] = exp(-0.5 / (sigma * sigma) * (double)(k * k)) / sum;
-        hipLaunchKernelGGL(rg_gauss_kernel, rg_grid((int64_t)hi * wi), dim3(kBlock), 0, s, cur, bufs[nb], hi, wi, axis, radius, w[0], w[1], w[2]);
+        radius[axis] = (int)(4.0 * sigma + 0.5);
+        if (radius[axis] > 2) return CT_E_BADARG;                     // halving pyramids never get here
+        double sum = 0.0;
+        for (int k = -radius[axis]; k <= radius[axis]; ++k) sum += exp(-0.5 / (sigma * sigma) * (double)(k * k));
+        for (int k = 0; k <= radius[axis]; ++k) wts[axis][k] = exp(-0.5 / (sigma * sigma) * (double)(k * k)) / sum;
+        filtered[axis] = true;
+    }
+    // (a fused gaussian + gaussian + bilinear kernel was tried: bitwise the same, 0.7 ms SLOWER per 1080p frame -- its 100 strided
+    // float64 gathers per output pixel coalesce badly; the three streaming launches stay)
+    const double *cur = src;
+    double *bufs[2] = {tmp0, tmp1};
+    int nb = 0;
+    for (int axis = 0; axis < 2; ++axis) {
+        if (!filtered[axis]) continue;
+        hipLaunchKernelGGL(rg_gauss_kernel, rg_grid((int64_t)hi * wi), dim3(kBlock), 0, s, cur, bufs[nb], hi, wi, axis, radius[axis], wts[axis][0],
+                           wts[axis][1], wts[axis][2]);
         CT_CHECK_LAUNCH();
         cur = bufs[nb];
         nb ^= 1;
@@ -179,6 +291,11 @@ int ct_regrain_f64(const double *img_in, const double *img_col, double *out, int
     if (!img_in || !img_col || !out || !nbits || height < 1 || width < 1 || n_nbits < 1 || n_nbits > kRgMaxLevels) return CT_E_BADARG;
     if (!ws || (reinterpret_cast<uintptr_t>(ws) & 15) || ws_bytes < ct_regrain_workspace_bytes(height, width)) return CT_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
+    static const bool attr_set = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(rg_sweepk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(7 * kRgMaxRegion * sizeof(double))) == hipSuccess;
+    }();
+    (void)attr_set;
     RgLevel lv[kRgMaxLevels];
     const int n = rg_levels(height, width, n_nbits, lv);
     double *p = reinterpret_cast<double *>(ws);
@@ -216,12 +333,23 @@ int ct_regrain_f64(const double *img_in, const double *img_col, double *out, int
         hipLaunchKernelGGL(rg_weights_kernel, rg_grid(px), dim3(kBlock), 0, s, in_l[l], wt_l[l], h, w, 30.0 * exp2(-(double)l));
         CT_CHECK_LAUNCH();
         const double *prev = start;
-        for (int i = 0; i < nbits[l]; ++i) {
+        static const int kblock = [] { const char *e = getenv("CT_HIP_REGRAIN_K"); const int v = e ? atoi(e) : kRgKMax; return v < 1 ? 1 : (v > kRgKMax ? kRgKMax : v); }();
+        // small levels: small tiles (a launch lasts as long as its slowest workgroup: k sweeps of region / 256 pixels per thread)
+        const int th = px > 200000 ? 16 : 8, tw = px > 200000 ? 32 : 16;
+        const int tiles_x = (w + tw - 1) / tw, tiles_y = (h + th - 1) / th;
+        for (int i = 0; i < nbits[l];) {
+            const int kk = nbits[l] - i < kblock ? nbits[l] - i : kblock;
             // ping-pong; the LAST sweep of level 0 lands in the caller's buffer
-            double *next = (l == 0 && i == nbits[l] - 1) ? out : ((prev == it_b[l]) ? it_a[l] : it_b[l]);
-            hipLaunchKernelGGL(rg_sweep_kernel, rg_grid(px), dim3(kBlock), 0, s, prev, in_l[l], col_l[l], wt_l[l], next, h, w);
+            double *next = (l == 0 && i + kk == nbits[l]) ? out : ((prev == it_b[l]) ? it_a[l] : it_b[l]);
+            if (kk == 1) {
+                hipLaunchKernelGGL(rg_sweep_kernel, rg_grid(px), dim3(kBlock), 0, s, prev, in_l[l], col_l[l], wt_l[l], next, h, w);
+            } else {
+                hipLaunchKernelGGL(rg_sweepk_kernel, dim3(tiles_x * tiles_y), dim3(kBlock), (size_t)7 * kRgMaxRegion * sizeof(double), s, prev, in_l[l],
+                                   col_l[l], wt_l[l], next, h, w, th, tw, kk, tiles_x);
+            }
             CT_CHECK_LAUNCH();
             prev = next;
+            i += kk;
         }
         if (nbits[l] == 0 && l == 0) {                                 // no sweep on the finest level: the start image is the result
             if (hipMemcpyAsync(out, prev, (size_t)px * 3 * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess) return (int)hipGetLastError();
