@@ -1,22 +1,23 @@
-// conv_ws.hip -- 3x3 stride-1 "same" convolution with <= 64 input channels on the bf16 matrix pipe, WEIGHTS STATIONARY.
+// conv_ws.hip -- 3x3 stride-1 "same" convolution with 32 < cin <= 64 input channels on the 16-bit matrix pipe, WEIGHTS STATIONARY.
 //
-// Same arithmetic as conv_split.hip (float32 operands as three bf16 pieces, six v_mfma_f32_32x32x16_bf16 per 16-channel
-// product, float32 accumulation), different dataflow.  conv_split shares one input tile between the four waves of a
-// workgroup and streams the weights of every tap through an LDS ring: one barrier per tap, a conversion phase between the
-// stages, two workgroups per CU competing for the matrix pipe -- measured 47 % MFMA-busy, 22 % of a wave's time in the
-// per-tap barriers, 13 % in the conversion phase (tools/prof_conv_split.py).  Here the contraction is split ACROSS the
-// waves instead: wave (c, m) of the eight owns input channels [16 c, 16 c + 16) and output channels [32 m, 32 m + 32) and
-// keeps the weights of all nine taps x three pieces of that block in registers (27 fragments = 108 VGPRs) for the lifetime
-// of a persistent workgroup (one per CU; the two waves of a chunk share a SIMD, so while one of them stages, writes or
-// reduces, the other one's MFMAs keep the matrix pipe busy).  A workgroup walks down a 32-pixel wide strip; per output row
-//   * the two waves of a chunk fetch the next input row of ITS 16 channels (float32 NCHW, 16-byte loads, half the columns
-//     each), split it in registers and write it into the chunk's four-row LDS ring [piece][k-half][column][8 channels];
-//   * every wave runs 9 taps x 6 MFMAs (B fragments = one conflict-free 16-byte LDS read each);
-//   * writes its 32 x 32 partial sums to LDS; after ONE barrier per row every wave adds the four partial sums of 8 output
-//     channels in a fixed order (chunk 0..3), applies bias / activation / ResB skip / clamp and stores 16-byte rows.
-// No weight traffic after the prologue, no per-tap barriers, the float32 -> bf16 split of a value happens once, by one wave.
-// (First version, one wave per SIMD with all 64 output channels: 39 % MFMA-busy -- the ~500 non-MFMA instructions of a row
-// ran beside nothing; profiles/r03_conv_ws_notes.)
+// Same idea as conv_split.hip -- float32 operands as short-mantissa pieces, float32 accumulation -- in two forms: three bf16
+// pieces / six v_mfma_f32_32x32x16_bf16 per 16-channel product (conv_split's arithmetic), or TWO fp16 pieces / three
+// v_mfma_f32_32x32x16_f16 with power-of-two scales per staged input row and per layer (the default, ct_conv3x3_ws16_f32; see the
+// comment at the kernel).  Different dataflow: conv_split shares one input tile between the four waves of a workgroup and
+// streams the weights of every tap through an LDS ring -- one barrier per tap, a conversion phase between the stages, two
+// workgroups per CU competing for the matrix pipe: 47 % MFMA-busy, 22 % of a wave's time in the per-tap barriers, 13 % in the
+// conversion phase (tools/prof_conv_split.py).  Here the contraction is split ACROSS the waves: wave (c, m) of the eight owns
+// input channels [16 c, 16 c + 16) and output channels [32 m, 32 m + 32) and keeps the weights of all nine taps of that block
+// in registers (18 or 27 fragments = 72 / 108 VGPRs) for the lifetime of a persistent workgroup (one per CU; the two waves of a
+// chunk share a SIMD).  A workgroup walks down a 32-pixel wide strip of a row segment; per output row (a "step") a wave runs
+//   X: the reduce of the PREVIOUS row (the four chunk sums of its 8 output channels in a fixed order, bias, activation, ResB
+//      skip, clamp, one 16-byte store per lane) issued between the MFMAs of this row (9 taps x 3 or 6), whose B fragments are
+//      conflict-free 16-byte LDS reads a tap row ahead; then its 32 x 32 partial sums -> LDS;
+//   Y: requests (skip row of the next step, input row four steps ahead, branch-free), the maximum of the row staged next (fp16
+//      form), the float32 -> pieces split of its half of the row requested two steps ago -> the chunk's four-row LDS ring;
+// the two waves of a SIMD run X and Y in opposite order and ONE barrier ends the step.  No weight traffic after the prologue,
+// no per-tap barriers, a value is split once, by one wave; strips are ordered so that neighbours meet in the same XCD's L2.
+// The measured steps that led here (one wave per SIMD: 39 % MFMA-busy; power limit of the bf16 form) are in DESIGN.md 4.4.
 // Rounding: float32 sums per chunk, then ((p0 + p1) + p2) + p3 + bias -- float32-grade like conv_split (not bitwise equal).
 #include "ct_common.h"
 #include "ct_conv.h"
