@@ -39,9 +39,17 @@ __device__ __forceinline__ double proj(const double *r, double x0, double x1, do
 }
 
 // per (pair, iteration) workspace record, all zero-initialised by one hipMemsetAsync per call
+// Same-address atomics from many workgroups serialise in the memory system (~20 ns each): the lo/hi keys and the histogram
+// counts are therefore kept in SHARDS (workgroup g updates shard g % S; readers take the max / the sum over the shards).
+// Integer max and integer add are order independent, so every bit of the result is unchanged; one pair's sweeps lose their
+// 8-15 us atomic tails (round 3: 2.9 k -> 4+ k pairs/s for one pair per call).
+constexpr int kMmShards = 16;
+constexpr int kHistShards = 8;
+
 struct IdtLayout {
-    unsigned long long *mm;  // [batch][n_iter][3][4] keys: max(-t) , max(t), max(-r), max(r)  (min via negation)
-    unsigned int *hist;      // [batch][n_iter][2][3][bins]
+    unsigned long long *mm;  // [batch][n_iter][kMmShards][3][4] keys: max(-t) , max(t), max(-r), max(r)  (min via negation)
+    unsigned int *hist;      // [batch][n_iter][kHistShards][2][3][bins]
+    unsigned int *hsum;      // [batch][n_iter][2][3][bins]: the shards added up by idt_lut_kernel (debug dump)
     double *lut;             // [batch][n_iter][3][bins][2]  (f[j], slope[j])
     double *par;             // [batch][n_iter][3][4]        (lo, hi, step, scale)
     size_t zero_bytes;       // leading bytes (mm + hist) that must be zero at call start
@@ -53,11 +61,14 @@ static IdtLayout idt_layout(void *ws, int batch, int n_iter, int bins) {
     char *p = reinterpret_cast<char *>(ws);
     size_t off = 0;
     l.mm = reinterpret_cast<unsigned long long *>(p + off);
-    off += (size_t)batch * n_iter * 3 * 4 * sizeof(unsigned long long);
+    off += (size_t)batch * n_iter * kMmShards * 3 * 4 * sizeof(unsigned long long);
     l.hist = reinterpret_cast<unsigned int *>(p + off);
-    off += (size_t)batch * n_iter * 2 * 3 * bins * sizeof(unsigned int);
+    off += (size_t)batch * n_iter * kHistShards * 2 * 3 * bins * sizeof(unsigned int);
     off = (off + 15) & ~(size_t)15;
     l.zero_bytes = off;
+    l.hsum = reinterpret_cast<unsigned int *>(p + off);
+    off += (size_t)batch * n_iter * 2 * 3 * bins * sizeof(unsigned int);
+    off = (off + 15) & ~(size_t)15;
     l.lut = reinterpret_cast<double *>(p + off);
     off += (size_t)batch * n_iter * 3 * bins * 2 * sizeof(double);
     l.par = reinterpret_cast<double *>(p + off);
@@ -156,8 +167,8 @@ __global__ __launch_bounds__(kIdtBlock) void idt_minmax_kernel(const T *__restri
                 const unsigned long long o = lds[(w * RG + q) * 6 + i];
                 m = o > m ? o : m;
             }
-            // mm[b][it][j][which*2 + {0: max(-d), 1: max(d)}]
-            unsigned long long *dst = mm + (((size_t)b * n_iter + it0 + q0 + q) * 3) * 4;
+            // mm[b][it][shard][j][which*2 + {0: max(-d), 1: max(d)}]
+            unsigned long long *dst = mm + ((((size_t)b * n_iter + it0 + q0 + q) * kMmShards + (blockIdx.x % kMmShards)) * 3) * 4;
             const int j = i >> 1, mmx = i & 1;
             atomicMax(dst + j * 4 + which * 2 + mmx, m);
         }
@@ -193,11 +204,30 @@ __device__ __forceinline__ int idt_bin(double x, int bins, double lo, double hi,
 // A8 part 1: (lo, hi, step, scale) of iteration `it`, axis j, from the min/max keys.  Every consumer evaluates this
 // itself (same arithmetic => same bits) instead of waiting for a one-workgroup kernel to publish them.
 // -------------------------------------------------------------------------------------------
-__device__ __forceinline__ void idt_params(const unsigned long long *__restrict__ mm, int b, int n_iter, int it, int j, int bins,
+__device__ __forceinline__ void idt_params(const unsigned long long *__restrict__ keys /* [3][4], shards reduced */, int j, int bins,
                                            double &lo, double &hi, double &step, double &scale) {
-    idt_range(mm + (((size_t)b * n_iter + it) * 3) * 4, j, lo, hi);
+    idt_range(keys, j, lo, hi);
     step = (hi - lo) / (double)bins;
     scale = (double)bins / (hi - lo);
+}
+
+// the 12 keys of (pair b, iteration it): max over the shards, by the whole workgroup (>= 192 threads), into keys[12] in LDS;
+// ends with a barrier
+__device__ __forceinline__ void idt_reduce_keys(const unsigned long long *__restrict__ mm, int b, int n_iter, int it,
+                                                unsigned long long *stage /* LDS [kMmShards * 12] */, unsigned long long *keys /* LDS [12] */) {
+    const unsigned long long *src = mm + ((size_t)b * n_iter + it) * kMmShards * 12;
+    if (threadIdx.x < kMmShards * 12) stage[threadIdx.x] = src[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        unsigned long long m = stage[threadIdx.x];
+#pragma unroll
+        for (int sh = 1; sh < kMmShards; ++sh) {
+            const unsigned long long o = stage[sh * 12 + threadIdx.x];
+            m = o > m ? o : m;
+        }
+        keys[threadIdx.x] = m;
+    }
+    __syncthreads();
 }
 
 // -------------------------------------------------------------------------------------------
@@ -209,14 +239,16 @@ __global__ __launch_bounds__(kIdtHistBlock) void idt_hist_kernel(const TT *__res
                                                              const unsigned long long *__restrict__ mm, int n_iter, int it, int bins,
                                                              unsigned int *__restrict__ hist, unsigned short *__restrict__ binidx) {
     extern __shared__ unsigned int lh[];  // [2][3][bins]
+    __shared__ unsigned long long kstage[kMmShards * 12], keys[12];
     const int b = blockIdx.y;
     for (int i = threadIdx.x; i < 6 * bins; i += kIdtHistBlock) lh[i] = 0;
     double r[9], lo[3], hi[3], step[3], scale[3];
 #pragma unroll
     for (int i = 0; i < 9; ++i) r[i] = rot[((size_t)b * n_iter + it) * 9 + i];
+    idt_reduce_keys(mm, b, n_iter, it, kstage, keys);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        idt_params(mm, b, n_iter, it, j, bins, lo[j], hi[j], step[j], scale[j]);
+        idt_params(keys, j, bins, lo[j], hi[j], step[j], scale[j]);
     }
     __syncthreads();
     const int64_t stride = (int64_t)gridDim.x * kIdtHistBlock;
@@ -240,7 +272,7 @@ __global__ __launch_bounds__(kIdtHistBlock) void idt_hist_kernel(const TT *__res
         }
     }
     __syncthreads();
-    unsigned int *gh = hist + ((size_t)b * n_iter + it) * 6 * bins;
+    unsigned int *gh = hist + (((size_t)b * n_iter + it) * kHistShards + (blockIdx.x % kHistShards)) * 6 * bins;
     for (int i = threadIdx.x; i < 6 * bins; i += kIdtHistBlock) {
         const unsigned int c = lh[i];
         if (c) atomicAdd(gh + i, c);
@@ -252,14 +284,28 @@ __global__ __launch_bounds__(kIdtHistBlock) void idt_hist_kernel(const TT *__res
 // -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kIdtBlock) void idt_lut_kernel(const unsigned int *__restrict__ hist, const unsigned long long *__restrict__ mm,
                                                             double *__restrict__ par, int n_iter, int it, int bins,
-                                                            double *__restrict__ lut) {
-    extern __shared__ double sm[];  // cp0[bins], cp1[bins], f[bins]
+                                                            double *__restrict__ lut, unsigned int *__restrict__ hsum) {
+    extern __shared__ double sm[];  // cp0[bins], cp1[bins], f[bins], then the two summed histograms as u32
     double *cp0 = sm, *cp1 = sm + bins, *f = sm + 2 * bins;
+    unsigned int *h0 = reinterpret_cast<unsigned int *>(sm + 3 * bins), *h1 = h0 + bins;
+    __shared__ unsigned long long kstage[kMmShards * 12], keys[12];
     const int j = blockIdx.x, b = blockIdx.y;
-    const unsigned int *h0 = hist + (((size_t)b * n_iter + it) * 6 + j) * bins;
-    const unsigned int *h1 = hist + (((size_t)b * n_iter + it) * 6 + 3 + j) * bins;
+    // the shards of the two histograms of this axis, added up (exact integers) -> LDS, and published for the debug dump
+    for (int i = threadIdx.x; i < bins; i += kIdtBlock) {
+        unsigned int a0 = 0, a1 = 0;
+#pragma unroll
+        for (int sh = 0; sh < kHistShards; ++sh) {
+            const unsigned int *g = hist + (((size_t)b * n_iter + it) * kHistShards + sh) * 6 * bins;
+            a0 += g[j * bins + i];
+            a1 += g[(3 + j) * bins + i];
+        }
+        h0[i] = a0; h1[i] = a1;
+        hsum[(((size_t)b * n_iter + it) * 6 + j) * bins + i] = a0;
+        hsum[(((size_t)b * n_iter + it) * 6 + 3 + j) * bins + i] = a1;
+    }
+    idt_reduce_keys(mm, b, n_iter, it, kstage, keys);        // ends with a barrier: h0 / h1 are complete too
     double lo, hi, step, scale;
-    idt_params(mm, b, n_iter, it, j, bins, lo, hi, step, scale);
+    idt_params(keys, j, bins, lo, hi, step, scale);
     if (threadIdx.x == 0) {             // published for the debug dump (ct_idt_debug.par)
         double *q = par + (((size_t)b * n_iter + it) * 3 + j) * 4;
         q[0] = lo; q[1] = hi; q[2] = step; q[3] = scale;
@@ -345,6 +391,7 @@ __global__ __launch_bounds__(kIdtBlock) void idt_apply_kernel(const TT *__restri
                                                               unsigned long long *__restrict__ mm) {
     extern __shared__ double2 sl[];  // [3][bins] (f, slope)
     __shared__ unsigned long long lds[4 * 6];
+    __shared__ unsigned long long kstage[kMmShards * 12], keys[12];
     const int b = blockIdx.y;
     {
         const double2 *g = reinterpret_cast<const double2 *>(lut + ((size_t)b * n_iter + it) * 3 * bins * 2);
@@ -358,12 +405,16 @@ __global__ __launch_bounds__(kIdtBlock) void idt_apply_kernel(const TT *__restri
         ri[i] = rinv[((size_t)b * n_iter + it) * 9 + i];
         rn[i] = has_next ? rot[((size_t)b * n_iter + it + 1) * 9 + i] : 0.0;
     }
+    idt_reduce_keys(mm, b, n_iter, it, kstage, keys);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        idt_params(mm, b, n_iter, it, j, bins, lo[j], hi[j], step[j], scale[j]);
+        idt_params(keys, j, bins, lo[j], hi[j], step[j], scale[j]);
     }
     __syncthreads();
-    unsigned long long key[6] = {0, 0, 0, 0, 0, 0};
+    // next iteration's lo/hi of the target: float64 v_min / v_max per pixel (a 64-bit integer max is a compare + two selects
+    // and the order-preserving key four more integer ops: ~50 instructions per pixel in round 2); the keys the integer
+    // atomicMax needs are built once per lane at the end, like in idt_minmax_kernel, non-finite projections poison the range
+    double nmn[3] = {INFINITY, INFINITY, INFINITY}, nmx[3] = {-INFINITY, -INFINITY, -INFINITY}, bad = 0.0;
     const TT *p = tgt + (size_t)b * n_t * 3;
     double *o = out + (size_t)b * n_t * 3;
     for (int64_t i = (int64_t)blockIdx.x * kIdtBlock + threadIdx.x; i < n_t; i += (int64_t)gridDim.x * kIdtBlock) {
@@ -395,13 +446,21 @@ __global__ __launch_bounds__(kIdtBlock) void idt_apply_kernel(const TT *__restri
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const double d = proj(rn + 3 * j, y0, y1, y2);
-                const unsigned long long kn = f64_key(-d), kx = f64_key(d);
-                key[2 * j] = kn > key[2 * j] ? kn : key[2 * j];
-                key[2 * j + 1] = kx > key[2 * j + 1] ? kx : key[2 * j + 1];
+                nmn[j] = fmin(nmn[j], d);
+                nmx[j] = fmax(nmx[j], d);
+                bad = fma(d, 0.0, bad);              // stays 0 unless d is NaN or infinite
             }
         }
     }
     if (has_next) {
+        unsigned long long key[6];
+        const bool poisoned = !(bad == 0.0);
+        const unsigned long long knan = f64_key(__longlong_as_double(0x7ff8000000000000ll));
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            key[2 * j] = poisoned ? knan : f64_key(-nmn[j]);
+            key[2 * j + 1] = poisoned ? knan : f64_key(nmx[j]);
+        }
 #pragma unroll
         for (int off = kWave / 2; off > 0; off >>= 1) {
 #pragma unroll
@@ -423,7 +482,7 @@ __global__ __launch_bounds__(kIdtBlock) void idt_apply_kernel(const TT *__restri
                 m = ov > m ? ov : m;
             }
             const int j = threadIdx.x >> 1, mmx = threadIdx.x & 1;
-            atomicMax(mm + (((size_t)b * n_iter + it + 1) * 3 + j) * 4 + mmx, m);   // target slots 0,1
+            atomicMax(mm + ((((size_t)b * n_iter + it + 1) * kMmShards + (blockIdx.x % kMmShards)) * 3 + j) * 4 + mmx, m);   // target slots 0,1
         }
     }
 }
@@ -503,8 +562,8 @@ static int idt_impl(const T *target, int64_t n_t, const T *reference, int64_t n_
                                n_iter, it, bins, l.hist, bi);
         }
         CT_CHECK_LAUNCH();
-        hipLaunchKernelGGL(idt_lut_kernel, dim3(3, batch), dim3(kIdtBlock), 3 * bins * sizeof(double), s, l.hist, l.mm,
-                           l.par, n_iter, it, bins, l.lut);
+        hipLaunchKernelGGL(idt_lut_kernel, dim3(3, batch), dim3(kIdtBlock), 3 * bins * sizeof(double) + 2 * bins * sizeof(unsigned int), s,
+                           l.hist, l.mm, l.par, n_iter, it, bins, l.lut, l.hsum);
         CT_CHECK_LAUNCH();
         const int rf = (round_dr_f32 && it == 0) ? 1 : 0;
         if (it == 0) {
@@ -518,7 +577,7 @@ static int idt_impl(const T *target, int64_t n_t, const T *reference, int64_t n_
     }
     if (dbg) {   // parity probes: device-to-device copies of the integer / LUT state
         if (dbg->hist &&
-            (e = hipMemcpyAsync(dbg->hist, l.hist, (size_t)batch * n_iter * 6 * bins * sizeof(unsigned int),
+            (e = hipMemcpyAsync(dbg->hist, l.hsum, (size_t)batch * n_iter * 6 * bins * sizeof(unsigned int),
                                 hipMemcpyDeviceToDevice, s)) != hipSuccess)
             return (int)e;
         if (dbg->lut && (e = hipMemcpyAsync(dbg->lut, l.lut, (size_t)batch * n_iter * 3 * bins * 2 * sizeof(double),
