@@ -92,3 +92,34 @@ def test_conv_ws16_entry_argument_checks(hip):
     assert lib.ct_conv3x3_ws16_f32(p, p, 0, p, null, p, 1, 32, 64, 8, 32, 0, 0, 0, 0, 0, null) == -1           # cin <= 32
     assert lib.ct_conv3x3_ws16_f32(p, p, 0, p, null, p, 1, 64, 64, 8, 30, 0, 0, 0, 0, 0, null) == -3           # W % 4
     assert lib.ct_conv3x3_ws16_f32(p, p, 0, p, null, p, 0, 64, 64, 8, 32, 0, 0, 0, 0, 0, null) == 0            # empty batch
+
+
+@pytest.mark.parametrize("k,c1,c2,c3", [(1, 64, 64, 1), (3, 32, 16, 5), (1, 16, 48, 33)])
+def test_conv_three_sources_equals_concat(hip, k, c1, c2, c3):
+    """ct_conv2d_split_f32 with three input tensors == the convolution of torch.cat([a, b, c], 1) (DCMCS3DI's
+    transfer[0] reads fea_left, fea_warped and the valid mask without the 129-channel concatenation); bitwise, since the
+    chunks of 16 channels and their order are the same."""
+    n, h, w, cout = 2, 20, 36, 64
+    a, b, c = rnd(n, c1, h, w), rnd(n, c2, h, w), rnd(n, c3, h, w)
+    cin = c1 + c2 + c3
+    wt, bias = rnd(cout, cin, k, k) / (cin * k * k) ** 0.5, rnd(cout)
+    wp, bp = hip.pack_conv_weight(wt.cuda(), bias.cuda())
+    cat = torch.cat([a, b, c], 1).cuda()
+    want = hip.conv2d(cat, wp, bp, cout, k, act=1)
+    got = hip.conv2d(a.cuda(), wp, bp, cout, k, act=1, x2=b.cuda(), x3=c.cuda())
+    same_kernel = not (k == 3 and 32 < cin <= 64)     # a single 3x3 input with 32 < cin <= 64 takes conv_ws (other arithmetic)
+    if same_kernel:
+        assert torch.equal(got, want)
+    ref = F.leaky_relu(F.conv2d(cat.double().cpu(), wt.double(), bias.double(), padding=k // 2), 0.01)
+    assert (got.double().cpu() - ref).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item())
+    # batch views as inputs (fea[:B] of the two-view tensor)
+    big = rnd(n + 1, c1, h, w).cuda()
+    got = hip.conv2d(big[:n], wp, bp, cout, k, x2=b.cuda(), x3=c.cuda())
+    want = hip.conv2d(torch.cat([big[:n], b.cuda(), c.cuda()], 1), wp, bp, cout, k)
+    assert torch.equal(got, want) if same_kernel else (got - want).abs().max().item() < 4e-6 * max(1.0, want.abs().max().item())
+    hip.set_conv_mode("exact")                       # no split kernel: the concatenation is materialised, same values to rounding
+    try:
+        ex = hip.conv2d(a.cuda(), wp, bp, cout, k, act=1, x2=b.cuda(), x3=c.cuda())
+    finally:
+        hip.set_conv_mode("split")
+    assert (ex.double().cpu() - ref).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item())
