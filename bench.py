@@ -270,6 +270,14 @@ def main():
             torch.cuda.synchronize()
             ts.append(ev[0].elapsed_time(ev[1]) * 1e-3)
             ta.append(ev[2].elapsed_time(ev[3]) * 1e-3)
+        # the same two sweeps without the fused metric (ct_reinhard_f32): what the apply sweep does on its own two planes
+        ts0, ta0 = [], []
+        if fused_psnr:
+            for i in range(min(n_prof, 20)):
+                ct_hip.reinhard(tgt, ref, out=out)
+                torch.cuda.synchronize()
+                ts0.append(ev[0].elapsed_time(ev[1]) * 1e-3)
+                ta0.append(ev[2].elapsed_time(ev[3]) * 1e-3)
         ct_hip.profile_events(None)
         t_stats, t_apply = float(np.mean(ts)), float(np.mean(ta))
         table = ct_hip.lab_mode() == "table"
@@ -313,6 +321,10 @@ def main():
                          "frac_of_peak": ALGO_BYTES_PER_PAIR * value / world / HBM_PEAK,
                          "sum_of_event_timed_kernels_ms": t_kernels * 1e3,
                          "note": "3 compulsory planes per pair over the whole step; value includes the per-frame metric (%s)" % (",".join(names) or "none")}}
+        if ta0:
+            roof["without_metric"] = {"note": "ct_reinhard_f32 (no fused PSNR), same tensors: the apply launch then moves exactly its two planes",
+                                      "apply_avg_launch_us": float(np.mean(ta0)) * 1e6, "apply_frac": 2 * B * PLANE_F32 / float(np.mean(ta0)) / HBM_PEAK,
+                                      "stats_avg_launch_us": float(np.mean(ts0)) * 1e6, "stats_frac": 2 * B * PLANE_F32 / float(np.mean(ts0)) / HBM_PEAK}
         # consistency of the timed region with the kernels it is made of (PSNR-only mode: two sweeps + a 5 us finish)
         if fused_psnr and dt / K > 1.3 * t_kernels + 30e-6:
             roof["warning"] = "ms_per_step %.3f exceeds 1.3 x the event-timed kernels (%.3f ms): host-side cost inside the timed region" % (

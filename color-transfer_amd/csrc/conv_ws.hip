@@ -30,7 +30,7 @@ constexpr int kWsTW = 32;                    // output columns of a strip (= MFM
 constexpr int kWsCols = 40;                  // staged columns x0-4 .. x0+35 (ten aligned groups of four)
 constexpr int kWsSlotMax = 3 * 2 * kWsCols;  // 16-byte entries of one input row of one chunk: [piece][k-half][column] (3 bf16 or 2 fp16 pieces)
 constexpr int kWsRing = 4;                   // input rows resident per wave (three in use, one being filled)
-constexpr int kWsPS = 36;                    // floats per row of a partial-sum tile (16-byte aligned, k-halves on disjoint banks)
+constexpr int kWsPS = 36;                    // floats per row of a partial-sum tile (16-byte aligned; 40 / 44 and s_setprio around X: no change)
 constexpr int kWsChunks = 4;                 // 16-channel chunks = SIMDs
 constexpr int kWsWaves = 8;                  // (chunk, 32-channel half of the outputs)
 
