@@ -353,6 +353,33 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
             const int cout_g = a.cout - grp * COUTP;
             const bool full = (cout_g >= COUTP);
             const int x4 = tx * kSpTW + 4 * (lane & 7);
+            if (a.rows_channels > 0) {
+                // token-rows output [N*H, W, rows_channels]: the lane's four consecutive channels of each 8-group are one 16-byte
+                // store at its pixel (no staging); the attention kernels read this layout, so the NCHW tensor and its transpose
+                // never exist
+                float *__restrict__ orow = a.out + (size_t)n * plane * a.rows_channels + a.rows_c0 + grp * COUTP;
+                const int x = tx * kSpTW + nl;
+#pragma unroll
+                for (int q = 0; q < RPW; ++q) {
+                    const int y = ty * kSpTH + wave * RPW + q;
+                    if (y < a.H && x < a.W) {
+                        float *__restrict__ op = orow + (size_t)(y * a.W + x) * a.rows_channels;
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int co = m * 32 + 8 * j + 4 * hl;
+                                float4 v = make_float4(acc[q][m][4 * j], acc[q][m][4 * j + 1], acc[q][m][4 * j + 2], acc[q][m][4 * j + 3]);
+                                if (a.act) {
+                                    v.x = split_act<GEN>(v.x, a.act); v.y = split_act<GEN>(v.y, a.act);
+                                    v.z = split_act<GEN>(v.z, a.act); v.w = split_act<GEN>(v.w, a.act);
+                                }
+                                if (full || co < cout_g) *reinterpret_cast<float4 *>(op + co) = v;
+                            }
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int q = 0; q < RPW; ++q) {
                 const int y = ty * kSpTH + wave * RPW + q;
@@ -425,7 +452,9 @@ int conv_split(const ConvArgs &a, int N, int kh, int kw, bool gen, hipStream_t s
                      ((reinterpret_cast<uintptr_t>(a.wp) & 15) == 0) &&
                      (!a.residual || (((reinterpret_cast<uintptr_t>(a.residual) & 15) == 0) && (a.res_bstride % 4 == 0)));
     if (!vec) return 1;
-    if (kh == 3 && kw == 3) {
+    if (a.rows_channels > 0 && ((a.rows_channels & 3) || (a.rows_c0 & 3) || a.rows_c0 + a.cout > a.rows_channels || a.residual || a.clamp))
+        return CT_E_BADARG;
+    if (kh == 3 && kw == 3 && a.rows_channels == 0) {
         const int rc = conv_ws(a, N, gen, s);
         if (rc != 1) return rc;
     }
@@ -460,6 +489,22 @@ int ct_conv2d_split_f32(const float *in, const float *in2, int cin1, const float
     a.cin = cin; a.cout = cout; a.H = h; a.W = w;
     a.in_bstride = in_bstride; a.out_bstride = out_bstride; a.res_bstride = res_bstride;
     a.act = act; a.clamp = clamp; a.groups = (cout + 63) / 64; a.prof = nullptr;
+    const int rc = ct::conv_split(a, n, kh, kw, true, (hipStream_t)stream);
+    return rc == 1 ? CT_E_BADARG : rc;
+}
+
+int ct_conv2d_split_rows_f32(const float *in, const void *wp_split, const float *bias, float *out_rows, int n, int cin, int cout, int h,
+                             int w, int kh, int kw, long long in_bstride, int rows_channels, int rows_c0, int act, void *stream) {
+    if (!in || !wp_split || !bias || !out_rows || n < 0 || cin < 1 || cout < 1 || h < 0 || w < 0 || act < 0 || act > 5) return CT_E_BADARG;
+    if (rows_channels < 4 || rows_c0 < 0) return CT_E_BADARG;
+    if (n == 0 || h == 0 || w == 0) return CT_OK;
+    ct::ConvArgs a;
+    a.in = in; a.in2 = nullptr; a.cin1 = cin; a.in2_bstride = 0;
+    a.wp = reinterpret_cast<const float *>(wp_split); a.bias = bias; a.residual = nullptr; a.out = out_rows;
+    a.cin = cin; a.cout = cout; a.H = h; a.W = w;
+    a.in_bstride = in_bstride; a.out_bstride = 0; a.res_bstride = 0;
+    a.act = act; a.clamp = 0; a.groups = (cout + 63) / 64; a.prof = nullptr;
+    a.rows_channels = rows_channels; a.rows_c0 = rows_c0;
     const int rc = ct::conv_split(a, n, kh, kw, true, (hipStream_t)stream);
     return rc == 1 ? CT_E_BADARG : rc;
 }

@@ -25,6 +25,8 @@ struct ConvArgs {
     long long in3_bstride = 0;
     int f16 = 0;                // conv_ws only: 1 = two fp16 pieces (weights scaled by 2^w_exp), 0 = three bf16 pieces
     int w_exp = 0;
+    int rows_channels = 0;      // split kernel only: > 0 = `out` is a token-rows tensor [N*H, W, rows_channels] and the result goes to its
+    int rows_c0 = 0;            // channels rows_c0 .. rows_c0 + cout (multiples of 4); no residual / clamp in this mode
 };
 
 // cnn.hip: stride-1, padding k/2, kernel 3x3 / 1x1 / 1x5 / 5x1, weights packed [group][tap][cin_pair][2][64];

@@ -18,7 +18,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CT_HIP_LIB") or os.path.join(_HERE, "libct_hip.so")   # CT_HIP_LIB: tuning builds only
 
-CT_ABI_VERSION = 3            # include/ct_hip.h: CT_ABI_VERSION; lib() refuses any other library
+CT_ABI_VERSION = 4            # include/ct_hip.h: CT_ABI_VERSION; lib() refuses any other library
 CT_LAB_STATS_STRIDE = 8
 CT_RGB_STATS_STRIDE = 16
 CT_WS_LAB_STATS, CT_WS_RGB_MEANCOV, CT_WS_REINHARD, CT_WS_IDT, CT_WS_REINHARD_PSNR = 0, 1, 2, 3, 4
@@ -696,6 +696,26 @@ def conv2d(x, wp, bias, cout, ksize, act=0, residual=None, clamp=False, out=None
     return out
 
 
+def conv2d_rows(x, wp, bias, cout, ksize, act=0, out=None, c0=0, channels=None):
+    """conv2d whose result is written as token rows: out[n*H + y, x, c0 + co] of a [N*H, W, channels] tensor (the layout the
+    streaming attention reads), so the NCHW tensor and its transpose are never made.  Returns None when the split kernel cannot
+    take the convolution (exact mode, W % 4): the caller then runs conv2d + the transpose."""
+    split = getattr(wp, "_ct_split", None)
+    n, cin, h, w = x.shape
+    if split is None or not x.is_cuda or x.dtype != torch.float32 or not _split_ok(x, None, None, ksize, ksize, 1, ksize // 2, ksize // 2):
+        return None
+    _check_device(x)
+    channels = int(channels if channels is not None else (out.shape[2] if out is not None else cout))
+    if out is None:
+        out = torch.empty((n * h, w, channels), dtype=torch.float32, device=x.device)
+    if (out.shape != (n * h, w, channels) or not out.is_contiguous() or out.dtype != torch.float32 or out.device != x.device or
+            channels % 4 or c0 % 4 or cout % 4 or c0 + cout > channels):
+        raise CtHipError("conv2d_rows: out must be a contiguous float32 [N*H, W, channels] tensor, channels / c0 / cout multiples of 4")
+    check(lib().ct_conv2d_split_rows_f32(_ptr(x), _ptr(split[0]), _ptr(split[1]), _ptr(out), n, cin, cout, h, w, ksize, ksize,
+                                         _nchw_bstride(x), channels, int(c0), int(act), _stream()))
+    return out
+
+
 def pam_attend(q, k, v, rgb, want_att=False):
     """softmax(q.k/c) @ [v | rgb] per image row (pasmnet/attention.py:39-41, utils.py:30,123-125)."""
     for t in (q, k, v, rgb):
@@ -737,6 +757,7 @@ def pam_valid(q, k, want_att=False):
 _c_f = ctypes.c_float
 SIGNATURES.update({
     "ct_gconv2d_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 10 + [_c_ll, _c_ll, _c_int, _c_p]),
+    "ct_conv2d_split_rows_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 7 + [_c_ll, _c_int, _c_int, _c_int, _c_p]),
     "ct_conv3x3_ws16_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p] + [_c_int] * 5 + [_c_ll, _c_ll, _c_ll, _c_int, _c_int, _c_p]),
     "ct_instance_norm_workspace_bytes": (ctypes.c_size_t, [_c_int]),
     "ct_instance_norm_f32": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_f, _c_int, _c_p, ctypes.c_size_t, _c_p]),
@@ -1084,32 +1105,45 @@ def pam_streaming(q, k, v, rgb, q_other, k_other):
     b, c, h, w = q.shape
     if c != 64 or v.shape[1] != 64:
         raise CtHipError("pam_streaming is built for 64 channels")
-    scale = 1.0 / c                                   # the reference scales by 1/c, not 1/sqrt(c) (attention.py:41)
+    vt = torch.empty((b * h, w, 96), dtype=torch.float32, device=q.device)
+    nchw_to_rows(v, vt, 0)
+    return pam_streaming_rows(nchw_to_rows(q), nchw_to_rows(k), vt, rgb, nchw_to_rows(q_other), nchw_to_rows(k_other))
 
-    def rows(t, out=None, c0=0):                      # [B,C,H,W] -> [B*H, W, C] tokens (data movement only)
-        ct = t.shape[1]
-        if out is None:
-            out = torch.empty((b * h, w, ct), dtype=torch.float32, device=t.device)
-        check(lib().ct_nchw_to_rows_f32(_ptr(t), _ptr(out), b, ct, h, w, _nchw_bstride(t), out.shape[2], c0, _stream()))
-        return out
+
+def nchw_to_rows(t, out=None, c0=0):
+    """[B,C,H,W] -> channels c0.. of a [B*H, W, C'] token-rows tensor (data movement only)"""
+    b, ct, h, w = t.shape
+    if out is None:
+        out = torch.empty((b * h, w, ct), dtype=torch.float32, device=t.device)
+    check(lib().ct_nchw_to_rows_f32(_ptr(t), _ptr(out), b, ct, h, w, _nchw_bstride(t), out.shape[2], c0, _stream()))
+    return out
+
+
+def pam_streaming_rows(qt, kt, vt, rgb, qo, ko):
+    """pam_streaming on token rows: qt, kt, qo, ko [B*H, W, 64] (contiguous; views of a larger rows tensor along dim 0 are fine);
+    vt [B*H, W, 96] with the value in channels 0..63 -- channels 64..95 are filled here (rgb [B,3,H,W] + zero padding)."""
+    b, _, h, w = rgb.shape
+    for t in (qt, kt, qo, ko):
+        if t.shape != (b * h, w, 64) or not t.is_contiguous() or t.dtype != torch.float32 or not t.is_cuda:
+            raise CtHipError("pam_streaming_rows needs contiguous float32 [B*H, W, 64] CUDA tensors")
+    if vt.shape != (b * h, w, 96) or not vt.is_contiguous() or vt.dtype != torch.float32:
+        raise CtHipError("pam_streaming_rows needs a contiguous float32 [B*H, W, 96] value tensor")
+    _f32c(rgb)
+    scale = 1.0 / 64                                  # the reference scales by 1/c, not 1/sqrt(c) (attention.py:41)
 
     def nchw(t, ct, c0):                              # [B*H, W, C'] tokens -> [B,ct,H,W] from channels c0..c0+ct
         out = torch.empty((b, ct, h, w), dtype=torch.float32, device=t.device)
         check(lib().ct_rows_to_nchw_f32(_ptr(t), _ptr(out), b, ct, h, w, ct * h * w, t.shape[2], c0, _stream()))
         return out
-    qt, kt = rows(q), rows(k)
-    vt = torch.empty((b * h, w, 96), dtype=torch.float32, device=q.device)
     vt[:, :, 67:] = 0.0                               # the 29 padding channels of the 96-channel value
-    rows(v, vt, 0)
-    rows(rgb, vt, 64)
-    out = torch.empty((b * h, w, 96), dtype=torch.float32, device=q.device)
+    nchw_to_rows(rgb, vt, 64)
+    out = torch.empty((b * h, w, 96), dtype=torch.float32, device=qt.device)
     check(lib().ct_attention_rows64_f32(_ptr(qt), _ptr(kt), _ptr(vt), _ptr(out), _c_p(0), b * h, w, scale, _stream()))
     fea = nchw(out, 64, 0)
     wrgb = nchw(out, 3, 64)
-    qo, ko = rows(q_other), rows(k_other)
-    stats = torch.empty((b * h, w, 2), dtype=torch.float32, device=q.device)
+    stats = torch.empty((b * h, w, 2), dtype=torch.float32, device=qt.device)
     check(lib().ct_attention_rows64_f32(_ptr(qo), _ptr(ko), _c_p(0), _c_p(0), _ptr(stats), b * h, w, scale, _stream()))
-    colsum = torch.empty((b * h, w), dtype=torch.float32, device=q.device)
+    colsum = torch.empty((b * h, w), dtype=torch.float32, device=qt.device)
     check(lib().ct_attention_colsum64_f32(_ptr(qo), _ptr(ko), _ptr(stats), _ptr(colsum), b * h, w, scale, _stream()))
     colsum = colsum.view(b, 1, h, w)
     valid = (colsum > 0.1).float()                    # threshold only (utils.py:34); the sums come from the kernel

@@ -14,7 +14,7 @@ import torch
 
 import ct_hip
 from pasmnet.attention import PAB
-from pasmnet.backbone import ResB, conv_forward, resb_forward
+from pasmnet.backbone import ResB, conv_forward, conv_forward_rows, resb_forward
 
 
 def sequential_forward(seq, x):
@@ -57,21 +57,28 @@ class DCMCS3DI(torch.nn.Module):
         both = torch.cat([left, right], dim=0)
         fea = sequential_forward(self.extraction, both)                    # dcmcs3di.py:54-55
         head = resb_forward(self.matcher.head, fea)                        # attention.py:35-36
-        q = conv_forward(self.matcher.query, head)                         # attention.py:39,44
-        k = conv_forward(self.matcher.key, head)                           # attention.py:40,45
         fea_left, fea_right = fea[:B], fea[B:]
-        v = conv_forward(self.matcher.value, fea_right)                    # dcmcs3di.py:58
+        H, W = left.shape[2], left.shape[3]
+        if want_att or want_valid_right:
+            q = conv_forward(self.matcher.query, head)                     # attention.py:39,44
+            k = conv_forward(self.matcher.key, head)                       # attention.py:40,45
         if want_att:
             # the [B,H,W,W] maps are wanted: LDS-tile kernels that can write them out
+            v = conv_forward(self.matcher.value, fea_right)                # dcmcs3di.py:58
             # right-to-left: Q(left) . K(right)
             fea_warped, warped_rgb, att_r2l = ct_hip.pam_attend(q[:B], k[B:], v, right, want_att=True)
             # left-to-right softmax, column sums -> valid mask of the LEFT view (utils.py:31,34-35)
             valid_left, colsum_left, att_l2r = ct_hip.pam_valid(q[B:], k[:B], want_att=True)
         else:
-            # streaming (online-softmax) kernels: no score tile in LDS, any width, K/V rows fetched with 16-byte loads
+            # streaming (online-softmax) kernels: no score tile in LDS, any width, K/V rows fetched with 16-byte loads.  They read
+            # token rows [B*H, W, C]; the three 1x1 convolutions store that layout from their epilogues (no NCHW q/k/v, no
+            # transposes)
             att_r2l = att_l2r = None
-            fea_warped, warped_rgb, valid_left, colsum_left = ct_hip.pam_streaming(
-                q[:B].contiguous(), k[B:].contiguous(), v, right, q[B:].contiguous(), k[:B].contiguous())
+            qt = conv_forward_rows(self.matcher.query, head)               # [2B*H, W, 64]: Q(left) rows then Q(right) rows
+            kt = conv_forward_rows(self.matcher.key, head)
+            vt = conv_forward_rows(self.matcher.value, fea_right, channels=96)
+            n = B * H
+            fea_warped, warped_rgb, valid_left, colsum_left = ct_hip.pam_streaming_rows(qt[:n], kt[n:], vt, right, qt[n:], kt[:n])
         # dcmcs3di.py:59,47: transfer[0] (1x1, 129 -> 64) reads cat([fea_left, fea_warped, valid_left]) straight from its
         # three tensors (a three-source K loop in ct_conv2d_split_f32; the 129-channel tensor is never built)
         x = conv_forward(self.transfer[0], fea_left, x2=fea_warped, x3=valid_left)

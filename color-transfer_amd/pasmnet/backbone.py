@@ -31,6 +31,19 @@ def conv_forward(conv, x, act=0, residual=None, clamp=False, out=None, x2=None, 
                          x2=x2, x3=x3)
 
 
+def conv_forward_rows(conv, x, out=None, c0=0, channels=None):
+    """conv_forward writing token rows [N*H, W, channels] (channels c0 .. c0 + cout) for the streaming attention: the split
+    kernel's epilogue stores that layout directly; otherwise (exact mode, W % 4) the NCHW result is transposed"""
+    wp, bias = packed_weights(conv)
+    rows = ct_hip.conv2d_rows(x, wp, bias, conv.out_channels, conv.kernel_size[0], out=out, c0=c0, channels=channels)
+    if rows is None:
+        n, _, h, w = x.shape
+        if out is None:
+            out = torch.empty((n * h, w, channels or conv.out_channels), dtype=torch.float32, device=x.device)
+        rows = ct_hip.nchw_to_rows(conv_forward(conv, x), out, c0)
+    return rows
+
+
 def resb_forward(block, x, out=None):
     """x + conv(LeakyReLU(conv(x)))  (pasmnet/backbone.py:14-15): two launches, the skip rides in the second conv's epilogue"""
     hidden = conv_forward(block.body[0], x, act=1)

@@ -33,9 +33,9 @@ extern "C" {
 #define CT_E_WORKSPACE (-2)  /* workspace too small / misaligned */
 #define CT_E_ALIGN (-3)      /* image base not aligned to its element size */
 
-/* bumped whenever an entry point changes its argument list (2: ct_attention_tokens_f32 gained kv_shift; 3: round 3);
+/* bumped whenever an entry point changes its argument list (2: ct_attention_tokens_f32 gained kv_shift; 3: round 3; 4: ct_conv2d_split_rows_f32);
  * the ctypes binding refuses a library whose ct_abi_version() differs */
-#define CT_ABI_VERSION 3
+#define CT_ABI_VERSION 4
 
 /* doubles per image in a stats record written by ct_lab_stats / ct_rgb_meancov */
 #define CT_LAB_STATS_STRIDE 8  /* mean[3], std[3] (population, ddof 0), n, 0           */
@@ -243,6 +243,14 @@ int ct_conv2d_split_f32(const float *in, const float *in2, int cin1, const float
                         const float *bias, const float *residual, float *out, int n, int cin, int cout, int h, int w, int kh,
                         int kw, long long in_bstride, long long in2_bstride, long long in3_bstride, long long out_bstride,
                         long long res_bstride, int act, int clamp, void *stream);
+
+/* ct_conv2d_split_f32 of one input tensor with the result stored as TOKEN ROWS: out_rows[(n*h + y)*w + x][rows_c0 + co] of a
+ * [n*h, w, rows_channels] tensor (rows_channels, rows_c0, cout multiples of 4; rows_c0 + cout <= rows_channels).  The query / key /
+ * value 1x1 convolutions of the parallax attention (pasmnet/attention.py:39-40,44-45, dcmcs3di.py:58) write the layout
+ * ct_attention_rows64_f32 reads, so their NCHW tensors and the transposes never exist.  No residual / clamp in this form. */
+int ct_conv2d_split_rows_f32(const float *in, const void *wp_split, const float *bias, float *out_rows, int n, int cin, int cout,
+                             int h, int w, int kh, int kw, long long in_bstride, int rows_channels, int rows_c0, int act,
+                             void *stream);
 
 /* The ResB convolutions (3x3, stride 1, padding 1, 32 < cin <= 64; reference pasmnet/backbone.py:8-15, unimatch/backbone.py
  * residual blocks) on the weight-stationary kernel of csrc/conv_ws.hip with float32 operands as TWO fp16 pieces and three

@@ -123,3 +123,68 @@ def test_conv_three_sources_equals_concat(hip, k, c1, c2, c3):
     finally:
         hip.set_conv_mode("split")
     assert (ex.double().cpu() - ref).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("k,cin,cout,channels,c0,act", [(1, 64, 64, 64, 0, 0), (1, 64, 64, 96, 0, 0), (1, 64, 32, 96, 64, 1),
+                                                      (3, 32, 64, 64, 0, 1), (1, 129, 132, 136, 4, 0), (1, 16, 4, 8, 4, 0)])
+def test_conv_rows_output_equals_transposed_nchw(hip, k, cin, cout, channels, c0, act):
+    """ct_conv2d_split_rows_f32 (the q / k / v convolutions of the parallax attention store token rows from their
+    epilogue) == the NCHW convolution followed by the transpose, bitwise where the same kernel computes both; the other channels
+    of the rows tensor are not touched; ragged tiles, several output groups, partial 32-channel tiles, batch views."""
+    n, h, w = 3, 21, 44
+    x = rnd(n + 1, cin, h, w).cuda()[1:]                   # a batch view
+    wt, bias = rnd(cout, cin, k, k) / (cin * k * k) ** 0.5, rnd(cout)
+    wp, bp = hip.pack_conv_weight(wt.cuda(), bias.cuda())
+    rows = torch.full((n * h, w, channels), 7.0, device="cuda")
+    got = hip.conv2d_rows(x, wp, bp, cout, k, act=act, out=rows, c0=c0)
+    assert got is rows
+    want = hip.conv2d(x, wp, bp, cout, k, act=act)      # 3x3 with cin <= 32: the tile kernel here too (conv_ws starts at cin 33)
+    want_rows = want.permute(0, 2, 3, 1).reshape(n * h, w, cout)
+    assert torch.equal(rows[:, :, c0:c0 + cout], want_rows)
+    keep = torch.ones(channels, dtype=torch.bool)
+    keep[c0:c0 + cout] = False
+    assert (rows[:, :, keep.cuda()] == 7.0).all()
+    ref = F.conv2d(x.double().cpu(), wt.double(), bias.double(), padding=k // 2)
+    ref = F.leaky_relu(ref, 0.01) if act else ref
+    assert (want.double().cpu() - ref).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item())
+
+
+def test_conv_rows_argument_checks_and_fallback(hip):
+    x = rnd(1, 64, 8, 32).cuda()
+    wt, bias = rnd(64, 64, 1, 1), rnd(64)
+    wp, bp = hip.pack_conv_weight(wt.cuda(), bias.cuda())
+    with pytest.raises(hip.CtHipError):
+        hip.conv2d_rows(x, wp, bp, 64, 1, out=torch.empty(8, 32, 66, device="cuda"))           # channels % 4
+    with pytest.raises(hip.CtHipError):
+        hip.conv2d_rows(x, wp, bp, 64, 1, out=torch.empty(8, 32, 96, device="cuda"), c0=36)    # c0 + cout > channels
+    assert hip.conv2d_rows(rnd(1, 64, 8, 30).cuda(), wp, bp, 64, 1) is None                    # W % 4: the caller transposes
+    hip.set_conv_mode("exact")
+    try:
+        assert hip.conv2d_rows(x, wp, bp, 64, 1) is None
+    finally:
+        hip.set_conv_mode("split")
+    lib, p, null = hip.lib(), x.data_ptr(), None
+    assert lib.ct_conv2d_split_rows_f32(p, p, p, p, 1, 64, 64, 8, 32, 1, 1, 64 * 8 * 32, 66, 0, 0, null) == -1
+    assert lib.ct_conv2d_split_rows_f32(p, p, p, p, 1, 64, 64, 8, 32, 1, 1, 64 * 8 * 32, 64, 4, 0, null) == -1
+    assert lib.ct_conv2d_split_rows_f32(p, p, p, p, 0, 64, 64, 8, 32, 1, 1, 64 * 8 * 32, 64, 0, 0, null) == 0
+
+
+def test_dcmcs3di_rows_path_equals_transposed_path(hip):
+    """the forward pass with q / k / v written as rows by the convolutions == the one that transposes NCHW q / k / v (bitwise:
+    the same values reach the attention kernels)"""
+    from methods.dcmcs3di import DCMCS3DI
+    from pasmnet.backbone import conv_forward
+    torch.manual_seed(3)
+    net = DCMCS3DI(extraction_layers=2, transfer_layers=1).cuda().eval()
+    left, right = torch.rand(1, 3, 24, 64, device="cuda"), torch.rand(1, 3, 24, 64, device="cuda")
+    parts = net.forward_parts(left, right)
+    both = torch.cat([left, right], 0)
+    from methods.dcmcs3di import sequential_forward
+    from pasmnet.backbone import resb_forward
+    fea = sequential_forward(net.extraction, both)
+    head = resb_forward(net.matcher.head, fea)
+    q, k = conv_forward(net.matcher.query, head), conv_forward(net.matcher.key, head)
+    v = conv_forward(net.matcher.value, fea[1:])
+    fw, wrgb, valid, colsum = hip.pam_streaming(q[:1].contiguous(), k[1:].contiguous(), v, right, q[1:].contiguous(), k[:1].contiguous())
+    assert torch.equal(parts["fea_warped"], fw) and torch.equal(parts["warped_rgb"], wrgb)
+    assert torch.equal(parts["colsum_left"], colsum) and torch.equal(parts["valid_left"], valid)
