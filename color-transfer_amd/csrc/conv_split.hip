@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
             for (int c = 0; c < half_tile_cycles; c += 64 * 64) __builtin_amdgcn_s_sleep(64);
         }
     }
-    const bool res_in_acc = (a.residual != nullptr) && (a.act == 0);
+    const bool res_in_acc = (a.residual != nullptr) && (a.act == 0 || a.res_pre);
     auto init_acc = [&](int k) {   // raw float4 rows of the skip tensor (or zeros); finish_acc() re-lays them out
         const int tg = tile_id(k), t = tg / a.groups, grp = tg - t * a.groups;
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
@@ -454,7 +454,7 @@ int conv_split(const ConvArgs &a, int N, int kh, int kw, bool gen, hipStream_t s
     if (!vec) return 1;
     if (a.rows_channels > 0 && ((a.rows_channels & 3) || (a.rows_c0 & 3) || a.rows_c0 + a.cout > a.rows_channels || a.residual || a.clamp))
         return CT_E_BADARG;
-    if (kh == 3 && kw == 3 && a.rows_channels == 0) {
+    if (kh == 3 && kw == 3 && a.rows_channels == 0 && !a.res_pre) {
         const int rc = conv_ws(a, N, gen, s);
         if (rc != 1) return rc;
     }
@@ -477,7 +477,7 @@ extern "C" {
 int ct_conv2d_split_f32(const float *in, const float *in2, int cin1, const float *in3, int cin2, const void *wp_split, const float *bias,
                         const float *residual, float *out, int n, int cin, int cout, int h, int w, int kh, int kw, long long in_bstride,
                         long long in2_bstride, long long in3_bstride, long long out_bstride, long long res_bstride, int act, int clamp,
-                        void *stream) {
+                        int res_pre_act, void *stream) {
     if (!in || !wp_split || !bias || !out || n < 0 || cin < 1 || cout < 1 || h < 0 || w < 0 || act < 0 || act > 5) return CT_E_BADARG;
     if (in2 && (cin1 < 16 || cin1 >= cin || (cin1 % 16))) return CT_E_BADARG;
     if (in3 && (!in2 || cin2 <= cin1 || cin2 >= cin || (cin2 % 16))) return CT_E_BADARG;
@@ -489,6 +489,7 @@ int ct_conv2d_split_f32(const float *in, const float *in2, int cin1, const float
     a.cin = cin; a.cout = cout; a.H = h; a.W = w;
     a.in_bstride = in_bstride; a.out_bstride = out_bstride; a.res_bstride = res_bstride;
     a.act = act; a.clamp = clamp; a.groups = (cout + 63) / 64; a.prof = nullptr;
+    a.res_pre = (residual && res_pre_act) ? 1 : 0;
     const int rc = ct::conv_split(a, n, kh, kw, true, (hipStream_t)stream);
     return rc == 1 ? CT_E_BADARG : rc;
 }

@@ -26,6 +26,7 @@ struct ConvArgs {
     int f16 = 0;                // conv_ws only: 1 = two fp16 pieces (weights scaled by 2^w_exp), 0 = three bf16 pieces
     int w_exp = 0;
     int rows_channels = 0;      // split kernel only: > 0 = `out` is a token-rows tensor [N*H, W, rows_channels] and the result goes to its
+    int res_pre = 0;            // split kernel only: 1 = `residual` is added BEFORE the activation (a pre-computed partial convolution)
     int rows_c0 = 0;            // channels rows_c0 .. rows_c0 + cout (multiples of 4); no residual / clamp in this mode
 };
 

@@ -523,7 +523,7 @@ SIGNATURES.update({
                                _c_ll, _c_int, _c_int, _c_p]),
     "ct_pam_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
     "ct_conv2d_split_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int,
-                                     _c_int, _c_int, _c_ll, _c_ll, _c_ll, _c_ll, _c_ll, _c_int, _c_int, _c_p]),
+                                     _c_int, _c_int, _c_ll, _c_ll, _c_ll, _c_ll, _c_ll, _c_int, _c_int, _c_int, _c_p]),
     "ct_pam_attend_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "ct_pam_valid_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_sz, _c_p]),
 })
@@ -622,13 +622,13 @@ def _split_ok(x, out, residual, kh, kw, stride, ph, pw):
     return True
 
 
-def _conv_split(x, split, cout, kh, kw, act, residual, clamp, out, x2=None, x3=None):
+def _conv_split(x, split, cout, kh, kw, act, residual, clamp, out, x2=None, x3=None, res_pre=False):
     ws, b64 = split[0], split[1]
     n, cin1, h, w = x.shape
     cin2 = cin1 + (x2.shape[1] if x2 is not None else 0)
     cin = cin2 + (x3.shape[1] if x3 is not None else 0)
     rs = _nchw_bstride(residual) if residual is not None else 0
-    if x2 is None and _ws16_ok(x, split, kh, kw):
+    if x2 is None and not res_pre and _ws16_ok(x, split, kh, kw):
         w16, w_exp = split[2]
         check(lib().ct_conv3x3_ws16_f32(_ptr(x), _ptr(w16), int(w_exp), _ptr(b64), _opt(residual), _ptr(out), n, cin, cout, h, w,
                                         _nchw_bstride(x), _nchw_bstride(out), rs, int(act), int(bool(clamp)), _stream()))
@@ -636,7 +636,7 @@ def _conv_split(x, split, cout, kh, kw, act, residual, clamp, out, x2=None, x3=N
     check(lib().ct_conv2d_split_f32(_ptr(x), _opt(x2), cin1, _opt(x3), cin2, _ptr(ws), _ptr(b64), _opt(residual), _ptr(out), n, cin,
                                     cout, h, w, kh, kw, _nchw_bstride(x), _nchw_bstride(x2) if x2 is not None else 0,
                                     _nchw_bstride(x3) if x3 is not None else 0, _nchw_bstride(out), rs, int(act), int(bool(clamp)),
-                                    _stream()))
+                                    int(bool(res_pre)), _stream()))
     return out
 
 
@@ -816,14 +816,26 @@ def pack_gconv_weight(weight, bias):
     return wp, b
 
 
-def gconv2d(x, wp, bias, cout, ksize, stride=1, padding=0, act=ACT_NONE, out=None, x2=None, residual=None):
+def gconv2d(x, wp, bias, cout, ksize, stride=1, padding=0, act=ACT_NONE, out=None, x2=None, residual=None, addend=None):
     """x2: optional second input tensor whose channels follow x's (torch.cat([x, x2], 1) without the copy when the
     split-bf16 kernel takes the convolution; otherwise the concatenation is materialised here).  residual: added to the
-    result (act must be ACT_NONE: MBConvBlock's identity skip)."""
+    result (act must be ACT_NONE: MBConvBlock's identity skip).  addend: a tensor of the output's shape added BEFORE the
+    activation (a pre-computed part of the convolution); split kernel only -- CtHipError otherwise."""
     kh, kw = (ksize, ksize) if isinstance(ksize, int) else ksize
     ph, pw = (padding, padding) if isinstance(padding, int) else padding
-    if residual is not None and (act != ACT_NONE or x2 is not None):
-        raise CtHipError("gconv2d: a residual needs act=ACT_NONE and a single input")
+    if residual is not None and (act != ACT_NONE or x2 is not None or addend is not None):
+        raise CtHipError("gconv2d: a residual needs act=ACT_NONE, a single input and no addend")
+    if addend is not None:
+        split = getattr(wp, "_ct_split", None)
+        n, c1, h, w = x.shape
+        if out is None:
+            out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+        ok = (split is not None and bias is not None and addend.shape == out.shape and addend.dtype == torch.float32 and
+              _split_ok(x, out, addend, kh, kw, stride, ph, pw) and
+              (x2 is None or (c1 % 16 == 0 and x2.data_ptr() % 16 == 0 and x2.stride(0) % 4 == 0)))
+        if not ok:
+            raise CtHipError("gconv2d: an addend needs the split kernel (conv mode 'split', stride 1, 'same' padding, W % 4 == 0)")
+        return _conv_split(x, split, cout, kh, kw, act, addend, False, out, x2=x2, res_pre=True)
     if x2 is not None:
         split = getattr(wp, "_ct_split", None)
         n, c1, h, w = x.shape

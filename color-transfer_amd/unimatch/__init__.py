@@ -292,20 +292,73 @@ class GMFlow(nn.Module):
         pos = _position_table(h // splits, w // splits, c // 2, f0.device).repeat(b, 1, splits, splits).contiguous()
         return ct_hip.eltwise(0, f0, pos), ct_hip.eltwise(0, f1, pos)
 
-    def _refine_iter(self, net, x, corr, flow, want_mask):               # reg_refine.py:58-122
+    def _gru_parts(self):
+        """SepConvGRU weights split by input block, packed once (rebuilt when a parameter changes).  The convolutions read
+        cat([h, inp, motion]) (reg_refine.py:43-55, 128 channels each); `inp` never changes over the refinement iterations and
+        the hidden state entering the horizontal half is the loop-invariant `net` (unimatch.py:318-323 recomputes it every
+        iteration), so   conv(cat) = [conv over the invariant blocks + bias: once per forward] + conv over the rest.
+        name -> (packed invariant part, packed varying part, first invariant channel, invariant channels)"""
+        gru = self.refine.gru
+        names = [n + s for s in ("1", "2") for n in ("convz", "convr", "convq")]
+        ver = tuple((getattr(gru, n).weight._version, getattr(gru, n).weight.data_ptr(), getattr(gru, n).bias._version,
+                     getattr(gru, n).bias.data_ptr()) for n in names)
+        hit = getattr(self, "_gru_packed", None)
+        if hit is None or hit[0] != ver:
+            parts = {}
+            for n in names:
+                w, b = getattr(gru, n).weight.detach(), getattr(gru, n).bias.detach()
+                if n in ("convz1", "convr1"):              # h = net AND inp are invariant: only the motion block varies
+                    fixed, rest = w[:, :256], w[:, 256:]
+                else:                                      # h varies (r * h, or the horizontal half's output)
+                    fixed, rest = w[:, 128:256], torch.cat((w[:, :128], w[:, 256:]), dim=1)
+                parts[n] = (ct_hip.pack_gconv_weight(fixed.contiguous(), b),
+                            ct_hip.pack_gconv_weight(rest.contiguous(), torch.zeros_like(b)))
+            hit = (ver, parts)
+            self._gru_packed = hit
+        return hit[1]
+
+    def _gru_invariants(self, net, inp):
+        """the loop-invariant partial sums of the six GRU convolutions (bias included), computed once per forward"""
+        gru, pre = self.refine.gru, {}
+        for n, ((wp, bp), _) in self._gru_parts().items():
+            conv = getattr(gru, n)
+            ks, pd = tuple(conv.kernel_size), tuple(conv.padding)
+            if n in ("convz1", "convr1"):
+                pre[n] = ct_hip.gconv2d(net, wp, bp, 128, ks, 1, pd, x2=inp)
+            else:
+                pre[n] = ct_hip.gconv2d(inp, wp, bp, 128, ks, 1, pd)
+        return pre
+
+    def _refine_iter(self, net, x, corr, flow, want_mask, pre=None):     # reg_refine.py:58-122
         """The reference's torch.cat's (reg_refine.py:43,51,72,75,77) never materialise: convs read two tensors, and
-        `x = [inp | motion features | flow]` is one buffer that `enc.conv` writes its 126 channels into."""
+        `x = [inp | motion features | flow]` is one buffer that `enc.conv` writes its 126 channels into.
+        pre: _gru_invariants(net, inp) -- the GRU convolutions then run over the varying input blocks only."""
         enc, gru = self.refine.encoder, self.refine.gru
         cor = _conv(enc.convc2, _conv(enc.convc1, corr, ACT_RELU), ACT_RELU)
         flo = _conv(enc.convf2, _conv(enc.convf1, flow, ACT_RELU), ACT_RELU)
         _conv(enc.conv, cor, ACT_RELU, x2=flo, out=x[:, 128:254])       # x[:, :128] = inp is loop invariant (caller)
         x[:, 254:] = flow
         h = net
-        for suf in ("1", "2"):
-            z = _conv(getattr(gru, "convz" + suf), h, ACT_SIGMOID, x2=x)
-            r = _conv(getattr(gru, "convr" + suf), h, ACT_SIGMOID, x2=x)
-            q = _conv(getattr(gru, "convq" + suf), ct_hip.eltwise(1, r, h), ACT_TANH, x2=x)
-            h = ct_hip.eltwise(2, z, h, q)
+        if pre is not None:
+            parts, mot = self._gru_parts(), x[:, 128:]
+
+            def part(name, a, act, x2=None):
+                conv = getattr(gru, name)
+                wp, bp = parts[name][1]
+                return ct_hip.gconv2d(a, wp, bp, 128, tuple(conv.kernel_size), 1, tuple(conv.padding), act=act, x2=x2, addend=pre[name])
+            for suf in ("1", "2"):
+                if suf == "1":
+                    z, r = part("convz1", mot, ACT_SIGMOID), part("convr1", mot, ACT_SIGMOID)
+                else:
+                    z, r = part("convz2", h, ACT_SIGMOID, x2=mot), part("convr2", h, ACT_SIGMOID, x2=mot)
+                q = part("convq" + suf, ct_hip.eltwise(1, r, h), ACT_TANH, x2=mot)
+                h = ct_hip.eltwise(2, z, h, q)
+        else:
+            for suf in ("1", "2"):
+                z = _conv(getattr(gru, "convz" + suf), h, ACT_SIGMOID, x2=x)
+                r = _conv(getattr(gru, "convr" + suf), h, ACT_SIGMOID, x2=x)
+                q = _conv(getattr(gru, "convq" + suf), ct_hip.eltwise(1, r, h), ACT_TANH, x2=x)
+                h = ct_hip.eltwise(2, z, h, q)
         delta = _conv(self.refine.flow_head.conv2, _conv(self.refine.flow_head.conv1, h, ACT_RELU))
         mask = _conv(self.refine.mask[2], _conv(self.refine.mask[0], h, ACT_RELU)) if want_mask else None
         return h, mask, delta
@@ -361,10 +414,13 @@ class GMFlow(nn.Module):
                 net0 = proj[:, :128].contiguous()                                        # loop invariant (unimatch.py:318-323)
                 xbuf = torch.empty((proj.shape[0], 256, h, w), dtype=torch.float32, device=proj.device)
                 xbuf[:, :128] = proj[:, 128:]                                            # inp; [128:254] motion features, [254:] flow
+                # split mode: the invariant input blocks of the GRU convolutions are convolved once (8 of the 18 block
+                # convolutions of an iteration); exact mode keeps the reference's form
+                pre = self._gru_invariants(net0, xbuf[:, :128]) if ct_hip.conv_mode() == "split" and w % 4 == 0 else None
                 for it in range(num_reg_refine):
                     corr = ct_hip.local_corr_flow(t0_ori, t1_ori, flow, 4)
                     last = it == num_reg_refine - 1
-                    _, up_mask, dflow = self._refine_iter(net0, xbuf, corr, flow, want_mask=last)
+                    _, up_mask, dflow = self._refine_iter(net0, xbuf, corr, flow, want_mask=last, pre=pre)
                     flow = ct_hip.eltwise(0, flow, dflow)
                     if dbg is not None:
                         dbg["flow_refine_%d" % it] = flow

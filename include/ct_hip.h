@@ -33,7 +33,7 @@ extern "C" {
 #define CT_E_WORKSPACE (-2)  /* workspace too small / misaligned */
 #define CT_E_ALIGN (-3)      /* image base not aligned to its element size */
 
-/* bumped whenever an entry point changes its argument list (2: ct_attention_tokens_f32 gained kv_shift; 3: round 3; 4: ct_conv2d_split_rows_f32);
+/* bumped whenever an entry point changes its argument list (2: ct_attention_tokens_f32 gained kv_shift; 3: round 3; 4: ct_conv2d_split_rows_f32, res_pre_act);
  * the ctypes binding refuses a library whose ct_abi_version() differs */
 #define CT_ABI_VERSION 4
 
@@ -238,11 +238,13 @@ int ct_conv2d_f32(const float *in, const float *wp, const float *bias, const flo
  * in2 != NULL: input channels [cin1, cin) come from in2 (cin1 % 16 == 0) -- torch.cat([a, b], dim=1) without the copy
  * (reg_refine.py:43,72,75: the GRU's hx / [r*h, x] and the motion encoder's [cor, flo]).
  * in3 != NULL (needs in2): channels [cin2, cin) come from in3 (cin2 % 16 == 0, cin1 < cin2 < cin): DCMCS3DI's
- * transfer[0] reads cat([fea_left, fea_warped, valid_left]) (methods/dcmcs3di.py:59,47) from its three tensors.            */
+ * transfer[0] reads cat([fea_left, fea_warped, valid_left]) (methods/dcmcs3di.py:59,47) from its three tensors.
+ * residual: added after the activation (ResB skip), or -- res_pre_act != 0 -- BEFORE it: a pre-computed partial convolution
+ * (the SepConvGRU's loop-invariant `inp` channels, reg_refine.py:25-55: conv(cat([h, inp, motion])) = conv_inp(inp) + conv(rest)). */
 int ct_conv2d_split_f32(const float *in, const float *in2, int cin1, const float *in3, int cin2, const void *wp_split,
                         const float *bias, const float *residual, float *out, int n, int cin, int cout, int h, int w, int kh,
                         int kw, long long in_bstride, long long in2_bstride, long long in3_bstride, long long out_bstride,
-                        long long res_bstride, int act, int clamp, void *stream);
+                        long long res_bstride, int act, int clamp, int res_pre_act, void *stream);
 
 /* ct_conv2d_split_f32 of one input tensor with the result stored as TOKEN ROWS: out_rows[(n*h + y)*w + x][rows_c0 + co] of a
  * [n*h, w, rows_channels] tensor (rows_channels, rows_c0, cout multiples of 4; rows_c0 + cout <= rows_channels).  The query / key /
