@@ -16,6 +16,7 @@
 //   convex_upsample, bilinear_resize, flow_warp, fb_check, gru ops, elementwise   utils.py:137-155, geometry.py
 #include "ct_common.h"
 #include "ct_conv.h"
+#include "ct_attention16.h"
 
 namespace ct {
 
@@ -1809,7 +1810,8 @@ int ct_attention_tokens_f32(const float *q, const float *k, const float *v, cons
     dim3 grid((len + 127) / 128, batch, nsplit);
     float *nostats = nullptr;
 #define CT_ATT(CVV, MAPPED) hipLaunchKernelGGL((ct::attention_tokens_kernel<128, CVV, MAPPED, true>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, region, rowmap, out, nostats, len, scale, ws, kv_shift, kv_total)
-    if (cv == 128) { if (rowmap) CT_ATT(128, true); else CT_ATT(128, false); }
+    if (ct::attention16_enabled()) ct::attention16_tokens128(q, k, v, region, rowmap, out, batch, len, cv, scale, nsplit, ws, kv_shift, kv_total, (hipStream_t)stream);
+    else if (cv == 128) { if (rowmap) CT_ATT(128, true); else CT_ATT(128, false); }
     else { if (rowmap) CT_ATT(2, true); else CT_ATT(2, false); }
 #undef CT_ATT
     CT_CHECK_LAUNCH();
@@ -1830,7 +1832,8 @@ int ct_attention_rows64_f32(const float *q, const float *k, const float *v, floa
     dim3 grid((len + 127) / 128, batch);
     const int *noreg = nullptr;
     if (v && (reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(out)) & 15) return CT_E_ALIGN;
-    if (v) hipLaunchKernelGGL((ct::attention_tokens_kernel<64, 96, false, true>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, noreg, noreg, out, stats, len, scale, (float *)nullptr);
+    if (ct::attention16_enabled()) ct::attention16_rows64(q, k, v, out, stats, batch, len, scale, (hipStream_t)stream);
+    else if (v) hipLaunchKernelGGL((ct::attention_tokens_kernel<64, 96, false, true>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, noreg, noreg, out, stats, len, scale, (float *)nullptr);
     else hipLaunchKernelGGL((ct::attention_tokens_kernel<64, 0, false, true>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, noreg, noreg, out, stats, len, scale, (float *)nullptr);
     CT_CHECK_LAUNCH();
     return CT_OK;
@@ -1842,7 +1845,8 @@ int ct_attention_colsum64_f32(const float *q, const float *k, const float *stats
     if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k)) & 15) return CT_E_ALIGN;
     if (batch == 0) return CT_OK;
     dim3 grid((len + 127) / 128, batch);
-    hipLaunchKernelGGL((ct::attention_colsum_kernel<64>), grid, dim3(256), 0, (hipStream_t)stream, q, k, stats, colsum, len, scale);
+    if (ct::attention16_enabled()) ct::attention16_colsum64(q, k, stats, colsum, batch, len, scale, (hipStream_t)stream);
+    else hipLaunchKernelGGL((ct::attention_colsum_kernel<64>), grid, dim3(256), 0, (hipStream_t)stream, q, k, stats, colsum, len, scale);
     CT_CHECK_LAUNCH();
     return CT_OK;
 }

@@ -260,3 +260,65 @@ def test_resampling_kernels(hip):
     fo, bo = hip.fb_check(a.cuda(), bw.cuda())
     rf, rb = og.forward_backward_consistency_check(a.double(), bw.double())
     assert (fo.cpu() == rf.float()).float().mean() > 0.99 and (bo.cpu() == rb.float()).float().mean() > 0.99
+
+
+@pytest.mark.parametrize("cv", [128, 2])
+def test_attention_tokens_wide_dynamic_range(hip, cv):
+    """the two-piece fp16 attention (csrc/attention16.hip) carries power-of-two scales per query row, per staged key tile and a
+    running one for the value tiles: operands of any magnitude, tiles of very different magnitude, all-zero tiles first"""
+    b, l = 2, 416
+    q, k, v = rnd(b, l, 128), rnd(b, l, 128), rnd(b, l, cv)
+    q[0] *= 3e-5; k[0] *= 2e4                                   # tiny queries against large keys: scores of order one
+    q[1, :100] *= 40.0; k[1, 200:232] *= 1e-3                   # rows / one whole key tile of another magnitude
+    v[0, :64] = 0.0                                             # two all-zero value tiles first, then tiny, then huge values
+    v[0, 64:128] *= 1e-12
+    v[0, 300:] *= 1e9
+    v[1] *= torch.logspace(-6, 6, l)[:, None]                   # the running value scale changes at nearly every tile
+    scores = torch.matmul(q.double(), k.double().transpose(1, 2)) / 128 ** 0.5
+    p = torch.softmax(scores, dim=-1)
+    ref = torch.matmul(p, v.double())
+    for nsplit in (1, 4):
+        out = hip.attention_tokens(q.cuda(), k.cuda(), v.cuda(), None, nsplit=nsplit).double().cpu()
+        assert_attention_bound(out, ref, scores, p, v, "nsplit=%d" % nsplit)
+
+
+def assert_attention_bound(out, ref, scores, p, v, what):
+    """float32 grade relative to what an output is made of (sum_j p_ij |v_jc|), with the score error (2^-22 of sum_c |q_c k_c|)
+    amplified by the softmax in proportion to the score magnitude, plus the fp16 floor of a probability: 2^-40 of the row's largest
+    one, times sum_j |v_jc| (attention16.hip; irrelevant unless values span ~10 decades along the keys)"""
+    mag = torch.matmul(p, v.double().abs())
+    smax = scores.abs().amax(dim=(1, 2), keepdim=True)
+    bound = (5e-6 + 4e-7 * smax) * mag + 2e-12 * v.double().abs().sum(dim=1, keepdim=True) + 1e-300
+    worst = ((out - ref).abs() / bound).max().item()
+    assert worst < 1.0, "%s: error / bound = %.3f" % (what, worst)
+
+
+def test_attention_rows64_wide_dynamic_range(hip):
+    """the 64-channel parallax attention (values of 96 channels, row statistics, column sums) on operands of any magnitude"""
+    n, w = 3, 200
+    q, k = rnd(n, w, 64), rnd(n, w, 64)
+    v = torch.zeros(n, w, 96)
+    v[:, :, :67] = rnd(n, w, 67)
+    q[0] *= 1e-4; k[0] *= 3e4
+    k[1, 64:96] *= 1e-4
+    v[1] *= torch.logspace(5, -5, w)[:, None]
+    v[2, :96] = 0.0
+    scale = 1.0 / 64
+    sc = torch.matmul(q.double(), k.double().transpose(1, 2)) * scale
+    p = torch.softmax(sc, dim=-1)
+    ref = torch.matmul(p, v.double())
+    lib = hip.lib()
+    out = torch.empty(n, w, 96, device="cuda")
+    qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
+    hip.check(lib.ct_attention_rows64_f32(qc.data_ptr(), kc.data_ptr(), vc.data_ptr(), out.data_ptr(), None, n, w, scale, None))
+    assert_attention_bound(out.double().cpu()[:, :, :67], ref[:, :, :67], sc, p, v[:, :, :67], "rows64")
+    stats = torch.empty(n, w, 2, device="cuda")
+    hip.check(lib.ct_attention_rows64_f32(qc.data_ptr(), kc.data_ptr(), None, None, stats.data_ptr(), n, w, scale, None))
+    m_ref = sc.max(dim=-1).values
+    l_ref = torch.exp(sc - m_ref[..., None]).sum(-1)
+    st = stats.double().cpu()
+    assert (st[..., 0] - m_ref).abs().max().item() < 2e-5 * max(1.0, m_ref.abs().max().item())
+    assert ((st[..., 1] - l_ref).abs() / l_ref).max().item() < 2e-5
+    colsum = torch.empty(n, w, device="cuda")
+    hip.check(lib.ct_attention_colsum64_f32(qc.data_ptr(), kc.data_ptr(), stats.data_ptr(), colsum.data_ptr(), n, w, scale, None))
+    assert (colsum.double().cpu() - p.sum(dim=1)).abs().max().item() < 2e-5 * max(1.0, p.sum(dim=1).max().item())
