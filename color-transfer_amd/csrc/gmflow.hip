@@ -442,11 +442,15 @@ __global__ __launch_bounds__(256) void linear_tokens_kernel(const float *__restr
 // One wave per token (2 channels per lane).
 __global__ __launch_bounds__(256) void layernorm_tokens_kernel(const float *__restrict__ x, const float *__restrict__ g,
                                                                const float *__restrict__ b, const float *__restrict__ res,
-                                                               float *__restrict__ out, long long T) {
+                                                               float *__restrict__ out, long long T, int partials) {
     const int lane = threadIdx.x & 63;
     const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
-    const float2 v = *reinterpret_cast<const float2 *>(x + t * 128 + 2 * lane);
+    float2 v = *reinterpret_cast<const float2 *>(x + t * 128 + 2 * lane);
+    for (int p = 1; p < partials; ++p) {       // the K-sliced linear's partial slabs [partials][T][128], added in slab order
+        const float2 u = *reinterpret_cast<const float2 *>(x + ((long long)p * T + t) * 128 + 2 * lane);
+        v.x += u.x; v.y += u.y;
+    }
     float s = v.x + v.y;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
@@ -1784,11 +1788,11 @@ int ct_rows_to_nchw_f32(const float *rows, float *nchw, int batch, int c, int h,
 }
 
 int ct_layernorm128_f32(const float *x, const float *gamma, const float *beta, const float *residual, float *out, long long tokens,
-                        void *stream) {
-    if (!x || !gamma || !beta || !out || tokens < 0) return CT_E_BADARG;
+                        int partials, void *stream) {
+    if (!x || !gamma || !beta || !out || tokens < 0 || partials < 1 || partials > 64) return CT_E_BADARG;
     if (tokens == 0) return CT_OK;
     hipLaunchKernelGGL(ct::layernorm_tokens_kernel, dim3((unsigned)((tokens + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma,
-                       beta, residual, out, tokens);
+                       beta, residual, out, tokens, partials);
     CT_CHECK_LAUNCH();
     return CT_OK;
 }

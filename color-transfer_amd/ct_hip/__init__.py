@@ -764,7 +764,8 @@ SIGNATURES.update({
     "ct_eltwise_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_f, _c_p]),
     "ct_linear_tokens_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p, ctypes.c_longlong, _c_int, _c_int, _c_int, _c_p]),
     "ct_linear_tokens_split_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p, ctypes.c_longlong, _c_int, _c_int, _c_int, _c_p]),
-    "ct_layernorm128_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_p]),
+    "ct_layernorm128_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_p]),
+    "ct_linear_ws16_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p]),
     "ct_attention_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int, _c_int, _c_int]),
     "ct_attention_tokens_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_int, _c_p,
                                          ctypes.c_size_t, ctypes.c_longlong, _c_p]),
@@ -969,16 +970,70 @@ def _packed_linear(weight):
     return hit[1]
 
 
-def linear_tokens(x, weight, bias=None, act=ACT_NONE, x2=None, mode=None):
+def pack_linear_weight_ws16(weight):
+    """Linear weight [N, K] -> ct_linear_ws16_f32 operand: slices of 256 input channels x 128 output features as fp16 (hi, lo) bit
+    patterns (int16) [slice][piece][k step 0..15][lane half 0..1][feature 0..127][8 channels] of weight * 2^w_exp, channel of
+    (k step s, half h, j) = 128 h + 8 s + j within the slice; K == 256: N / 128 feature slices, else (N == 128): K / 256 channel
+    slices.  Returns (image, w_exp); the largest |weight| lands in [2^11, 2^12)."""
+    n, k = weight.shape
+    w = weight.detach().float()
+    amax = float(w.abs().max())
+    w_exp = 0 if not (amax > 0 and amax < float("inf")) else 12 - (int(np.floor(np.log2(amax))) + 1)
+    w_exp = max(-100, min(100, w_exp))
+    ws = w * (2.0 ** w_exp)
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.float()).to(torch.float16)
+    pieces = torch.stack([hi, lo], dim=0).view(torch.int16)                # [2][N][K]
+    if k == 256 and n % 128 == 0:
+        img = pieces.reshape(2, n // 128, 128, 2, 16, 8).permute(1, 0, 4, 3, 2, 5)       # slice, piece, s, h, f, j
+    elif n == 128 and k % 256 == 0:
+        img = pieces.reshape(2, 128, k // 256, 2, 16, 8).permute(2, 0, 4, 3, 1, 5)
+    else:
+        raise CtHipError("pack_linear_weight_ws16: K == 256 with N % 128 == 0, or N == 128 with K % 256 == 0")
+    return img.contiguous(), w_exp
+
+
+def _packed_linear_ws16(weight):
+    ver = (weight._version, weight.data_ptr(), str(weight.device))
+    hit = getattr(weight, "_ct_lin_ws16", None)
+    if hit is None or hit[0] != ver:
+        hit = (ver, pack_linear_weight_ws16(weight))
+        weight._ct_lin_ws16 = hit
+    return hit[1]
+
+
+_lin_ws16 = os.environ.get("CT_HIP_LINEAR_WS16", "1") != "0"
+
+
+def set_linear_ws16(on):
+    """True (default): the FFN-shaped linears (K = 256 -> N % 128 = 0; K % 256 = 0 -> N = 128 as partial slabs) run in
+    ct_linear_ws16_f32 (weight slice resident in LDS, two fp16 pieces); False: everything in ct_linear_tokens_split_f32"""
+    global _lin_ws16
+    _lin_ws16 = bool(on)
+
+
+def linear_tokens(x, weight, bias=None, act=ACT_NONE, x2=None, mode=None, partials=False):
     """x [..., K1] channels-last tokens (optionally concatenated with x2 [..., K2] on the fly), weight [N, K1+K2]
-    (PyTorch layout) -> [..., N].  mode (default: conv_mode()): "split" = bf16 matrix pipe, float32-grade (K % 32 == 0; the
-    pre-split weight is cached on the weight tensor); "exact" = v_mfma_f32_32x32x2_f32."""
+    (PyTorch layout) -> [..., N].  mode (default: conv_mode()): "split" = 16-bit matrix pipe, float32-grade (K % 32 == 0; the
+    pre-split weight is cached on the weight tensor); "exact" = v_mfma_f32_32x32x2_f32.
+    partials=True: the result may come back as [P, ..., N] slabs whose sum over P is the result (K-sliced ct_linear_ws16_f32;
+    layernorm128 adds them on its way in) -- the caller must accept either shape (P == 1 slab otherwise)."""
     _f32c(x, weight, bias, x2)
     k1, n = x.shape[-1], weight.shape[0]
     k = k1 + (x2.shape[-1] if x2 is not None else 0)
     if weight.shape[1] != k or (x2 is not None and x2.shape[:-1] != x.shape[:-1]):
         raise CtHipError("linear_tokens: shape mismatch")
     t = x.numel() // k1
+    if (mode or _conv_mode) == "split" and _lin_ws16 and act in (ACT_NONE, ACT_GELU) and t >= 4096:
+        nsl = k == 256 and n % 128 == 0 and n // 128 in (1, 2, 4, 8) and (k1 == 128 if x2 is not None else True)
+        ksl = (not nsl) and partials and n == 128 and k % 256 == 0 and k // 256 in (2, 4, 8) and x2 is None and act == ACT_NONE
+        if nsl or ksl:
+            img, w_exp = _packed_linear_ws16(weight)
+            shape = ((k // 256,) if ksl else ()) + tuple(x.shape[:-1]) + (n,)
+            out = torch.empty(shape, dtype=torch.float32, device=x.device)
+            check(lib().ct_linear_ws16_f32(_ptr(x), _opt(x2), k1, _ptr(img), int(w_exp), _opt(bias), _ptr(out), t, k, n, int(act),
+                                           _stream()))
+            return out
     out = torch.empty(x.shape[:-1] + (n,), dtype=torch.float32, device=x.device)
     if (mode or _conv_mode) == "split" and k % 32 == 0:
         check(lib().ct_linear_tokens_split_f32(_ptr(x), _opt(x2), k1, _ptr(_packed_linear(weight)), _opt(bias), _ptr(out), t, k, n,
@@ -988,12 +1043,17 @@ def linear_tokens(x, weight, bias=None, act=ACT_NONE, x2=None, mode=None):
     return out
 
 
-def layernorm128(x, gamma, beta, residual=None):
+def layernorm128(x, gamma, beta, residual=None, partials=1):
+    """LayerNorm(128) (+ residual) of x [..., 128]; partials = P > 1: x is [P, ..., 128] and the input is the sum of its P slabs
+    (added in slab order: the K-sliced linear's partial results)"""
     _f32c(x, gamma, beta, residual)
     if x.shape[-1] != 128:
         raise CtHipError("layernorm128: last dim must be 128")
-    out = torch.empty_like(x)
-    check(lib().ct_layernorm128_f32(_ptr(x), _ptr(gamma), _ptr(beta), _opt(residual), _ptr(out), x.numel() // 128, _stream()))
+    partials = int(partials)
+    if partials < 1 or (partials > 1 and x.shape[0] != partials):
+        raise CtHipError("layernorm128: x must be [partials, ..., 128]")
+    out = torch.empty(x.shape[1:] if partials > 1 else x.shape, dtype=torch.float32, device=x.device)
+    check(lib().ct_layernorm128_f32(_ptr(x), _ptr(gamma), _ptr(beta), _opt(residual), _ptr(out), out.numel() // 128, partials, _stream()))
     return out
 
 

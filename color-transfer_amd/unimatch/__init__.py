@@ -272,8 +272,10 @@ class GMFlow(nn.Module):
         if m.no_ffn:
             return ct_hip.layernorm128(msg, g1, b1, residual=source)
         msg = ct_hip.layernorm128(msg, g1, b1)
-        x = _lin(m.mlp[2], _lin(m.mlp[0], source, act=ACT_GELU, x2=msg))      # mlp(cat([source, message])), no copy
-        return ct_hip.layernorm128(x, m.norm2.weight.detach(), m.norm2.bias.detach(), residual=source)
+        hid = _lin(m.mlp[0], source, act=ACT_GELU, x2=msg)                     # mlp(cat([source, message])), no copy
+        x = ct_hip.linear_tokens(hid, m.mlp[2].weight, m.mlp[2].bias, partials=True)
+        slabs = x.shape[0] if x.dim() == hid.dim() + 1 else 1                  # K-sliced: partial slabs, summed by the LayerNorm
+        return ct_hip.layernorm128(x, m.norm2.weight.detach(), m.norm2.bias.detach(), residual=source, partials=slabs)
 
     def _transformer(self, t0, t1, h, w, splits):                        # transformer.py:229-297
         # concat1 of the reference (transformer.py:281-287) = concat0 with the batch halves exchanged, re-built after every layer:

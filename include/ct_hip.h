@@ -33,7 +33,7 @@ extern "C" {
 #define CT_E_WORKSPACE (-2)  /* workspace too small / misaligned */
 #define CT_E_ALIGN (-3)      /* image base not aligned to its element size */
 
-/* bumped whenever an entry point changes its argument list (2: ct_attention_tokens_f32 gained kv_shift; 3: round 3; 4: ct_conv2d_split_rows_f32, res_pre_act);
+/* bumped whenever an entry point changes its argument list (2: ct_attention_tokens_f32 gained kv_shift; 3: round 3; 4: ct_conv2d_split_rows_f32, res_pre_act, ct_linear_ws16_f32, layernorm partials);
  * the ctypes binding refuses a library whose ct_abi_version() differs */
 #define CT_ABI_VERSION 4
 
@@ -312,9 +312,22 @@ int ct_linear_tokens_f32(const float *x, const float *x2, int k1, const float *w
  *   (ct_hip.pack_linear_weight_split).  k % 32 == 0.                                                              */
 int ct_linear_tokens_split_f32(const float *x, const float *x2, int k1, const void *wp, const float *bias, float *out,
                                long long tokens, int k, int n, int act, void *stream);
-/* LayerNorm(128, eps 1e-5, affine) on tokens, out = residual + LN(x) when residual != NULL (transformer.py:139-147) */
+/* The FFN-shaped linears (transformer.py:33-35,131-133: mlp = Linear(256 -> 1024) . GELU . Linear(1024 -> 128), no bias) with the
+ * weight slice RESIDENT in LDS and float32 operands as two fp16 pieces (csrc/linear_ws16.hip; three MFMAs per product, float32
+ * accumulation, 2^-22 relative dropped; power-of-two scales: one per layer on the weights, a running one per 32-token tile on the
+ * activations).  Two shapes:
+ *   k == 256, n % 128 == 0, n / 128 in {1,2,4,8}: out[tokens][n] = act(x' w^T + bias); x' = [x[t][0:128] | x2[t][0:128]] (k1 = 128)
+ *        or x[t][0:256] (x2 = NULL, k1 = 256);
+ *   n == 128, k % 256 == 0, k / 256 in {1,2,4,8}, x2 = NULL, act = 0: out = PARTIAL slabs [k/256][tokens][128] whose sum is the
+ *        result (bias in slab 0) -- ct_layernorm128_f32(partials = k/256) adds them in slab order on its way in.
+ * wp16: ct_hip.pack_linear_weight_ws16: fp16 bit patterns [slice][piece hi/lo][k step 0..15][lane half][feature 0..127][8 channels]
+ * of w * 2^w_exp, channel of (step s, half h, j) = 128 h + 8 s + j within the slice.  act: 0 none, 6 exact GELU.            */
+int ct_linear_ws16_f32(const float *x, const float *x2, int k1, const void *wp16, int w_exp, const float *bias, float *out,
+                       long long tokens, int k, int n, int act, void *stream);
+/* LayerNorm(128, eps 1e-5, affine) on tokens, out = residual + LN(x) when residual != NULL (transformer.py:139-147);
+ * partials > 1: x is [partials][tokens][128] and the normalised input is the sum of the slabs (added in slab order) */
 int ct_layernorm128_f32(const float *x, const float *gamma, const float *beta, const float *residual,
-                        float *out, long long tokens, void *stream);
+                        float *out, long long tokens, int partials, void *stream);
 /* single-head attention on tokens (C = 128), streaming softmax: out = softmax(q k^T * scale + mask) v.
  *   cv = 128 (swin window attention, attention.py:48-107) or 2 (global correlation -> expected coordinate,
  *   matching.py:10-39; flow propagation, attention.py:199-216).  region: NULL, or int32 [batch][len] ids;

@@ -322,3 +322,69 @@ def test_attention_rows64_wide_dynamic_range(hip):
     colsum = torch.empty(n, w, device="cuda")
     hip.check(lib.ct_attention_colsum64_f32(qc.data_ptr(), kc.data_ptr(), stats.data_ptr(), colsum.data_ptr(), n, w, scale, None))
     assert (colsum.double().cpu() - p.sum(dim=1)).abs().max().item() < 2e-5 * max(1.0, p.sum(dim=1).max().item())
+
+
+@pytest.mark.parametrize("t,k,n,act,two", [(4096, 256, 1024, 6, True), (5000, 256, 1024, 0, False), (4100, 256, 128, 6, True),
+                                           (4097, 1024, 128, 0, False), (9000, 512, 128, 0, False), (4096, 256, 512, 0, True)])
+def test_linear_ws16(hip, t, k, n, act, two):
+    """ct_linear_ws16_f32 (weight slice resident in LDS, two fp16 pieces): both slicings against float64 torch, token counts that
+    are not multiples of the 32-token tile, two-source rows, bias, GELU; K slices come back as partial slabs that
+    ct_layernorm128_f32 sums"""
+    x, w, b = rnd(t, k), rnd(n, k) / k ** 0.5, rnd(n)
+    ref = F.linear(x.double(), w.double(), b.double())
+    if act == 6:
+        ref = F.gelu(ref)
+    wc, xc = w.cuda(), x.cuda()
+    if two:
+        out = hip.linear_tokens(xc[:, :128].contiguous(), wc, b.cuda(), act=act, x2=xc[:, 128:].contiguous(), partials=True)
+    else:
+        out = hip.linear_tokens(xc, wc, b.cuda(), act=act, partials=True)
+    assert hasattr(wc, "_ct_lin_ws16")                                  # this shape took the resident-weight kernel
+    if k > 256:
+        assert out.shape == (k // 256, t, n)
+        g, be, res = rnd(128), rnd(128), rnd(t, 128)
+        ln = hip.layernorm128(out, g.cuda(), be.cuda(), residual=res.cuda(), partials=k // 256)
+        close(ln, res.double() + F.layer_norm(ref, (128,), g.double(), be.double()), "LN of the partial slabs", atol=2e-5, rtol=2e-5)
+        out = out.sum(dim=0)
+    close(out, ref, "linear_ws16")
+    hip.set_linear_ws16(False)                                          # the LDS-tiled kernel computes the same layer
+    try:
+        old = hip.linear_tokens(xc, wc, b.cuda(), act=act, partials=True)
+    finally:
+        hip.set_linear_ws16(True)
+    assert old.shape == (t, n)
+    close(old, ref, "linear_split")
+    wc.mul_(2.0)                                                        # the packed image follows in-place updates
+    out2 = hip.linear_tokens(xc, wc, None, partials=True)
+    out2 = out2.sum(dim=0) if out2.dim() == 3 else out2
+    close(out2, 2 * F.linear(x.double(), w.double()), "repacked after an in-place update")
+
+
+def test_linear_ws16_wide_dynamic_range(hip):
+    """the result does not depend on the magnitude of a token (per-token running power-of-two scale), nor on where in the row its
+    large channels sit (the scale drops in the middle of the contraction: the accumulators are rescaled)"""
+    t, k, n = 4096, 256, 256
+    x, w = rnd(t, k), rnd(n, k) / 16
+    scale = torch.pow(2.0, torch.randint(-20, 21, (t, 1), generator=G).float())
+    xs = x * scale
+    xs[::3, 200:] *= 4096.0                                              # large channels late in the row
+    xs[1::3, :16] *= 1e4                                                 # ... and early
+    xs[5] = 0.0
+    w2 = w * 1e-6                                                       # the per-layer weight scale
+    for ww in (w, w2):
+        ref = F.linear(xs.double(), ww.double())
+        out = hip.linear_tokens(xs.cuda(), ww.cuda(), None).cpu().double()
+        bound = F.linear(xs.double().abs(), ww.double().abs()) + 1e-300      # sum |x||w|: the natural error scale of a dot product
+        assert ((out - ref).abs() / bound).max().item() < 1e-6
+    xk = rnd(t, 1024) * scale
+    xk[::2, 700:] *= 1e3
+    wk = rnd(128, 1024) / 32
+    out = hip.linear_tokens(xk.cuda(), wk.cuda(), None, partials=True)
+    assert out.shape == (4, t, 128)
+    ref = F.linear(xk.double(), wk.double())
+    bound = F.linear(xk.double().abs(), wk.double().abs()) + 1e-300
+    assert ((out.sum(0).cpu().double() - ref).abs() / bound).max().item() < 1e-6
+    lib, p = hip.lib(), out.data_ptr()
+    assert lib.ct_linear_ws16_f32(p, None, 256, p, 0, None, p, 64, 256, 96, 0, None) == -1      # n % 128
+    assert lib.ct_linear_ws16_f32(p, None, 1024, p, 0, None, p, 64, 1024, 128, 6, None) == -1   # no activation on partial slabs
+    assert lib.ct_linear_ws16_f32(p, None, 256, p, 0, None, p, 0, 256, 128, 0, None) == 0       # no tokens

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Time nn.Linear on tokens, float32 MFMA ("exact") vs three-piece bf16 ("split"), on the GMFlow shapes at 960x540."""
+"""Time nn.Linear on tokens: float32 MFMA ("exact"), three-piece bf16 LDS-tiled ("split"), resident-weight two-piece fp16 where the
+shape has it ("ws16"), on the GMFlow shapes at 960x540."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "color-transfer_amd")):
@@ -14,7 +15,7 @@ def t_ms(fn, n=20):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 
 torch.manual_seed(0)
-MODES = sys.argv[1].split(",") if len(sys.argv) > 1 else ["exact", "split"]
+MODES = sys.argv[1].split(",") if len(sys.argv) > 1 else ["exact", "split", "ws16"]
 ROT = 6                                          # distinct input buffers, cycled: every call streams its tokens from HBM, as in the network
 SHAPES = [(T, k, n, act) for T in (14336, 114688) for k, n, act in ((128, 128, 0), (128, 384, 0), (256, 1024, 6), (256, 1024, 0), (1024, 128, 0))]
 if len(sys.argv) > 2:                            # one shape: T,K,N,act
@@ -27,13 +28,15 @@ for T, k, n, act in SHAPES:
         if act == 6: ref = torch.nn.functional.gelu(ref)
         line = "T=%6d K=%4d N=%4d" % (T, k, n)
         for mode in MODES:
-            out = ct_hip.linear_tokens(x, w, b, act=act, mode=mode)
-            err = (out.double() - ref).abs().max().item()
+            ct_hip.set_linear_ws16(mode == "ws16")
+            kw = dict(mode="split", partials=True) if mode == "ws16" else dict(mode=mode)
+            out = ct_hip.linear_tokens(x, w, b, act=act, **kw)
+            err = ((out.sum(0) if out.dim() == 3 else out).double() - ref).abs().max().item()
             del out
             it = [0]
             def call():
                 it[0] += 1
-                return ct_hip.linear_tokens(xs[it[0] % ROT], w, b, act=act, mode=mode)
+                return ct_hip.linear_tokens(xs[it[0] % ROT], w, b, act=act, **kw)
             ms = t_ms(call, 24)
             line += "  %s %.3f ms %6.1f TFLOP/s err %.2g" % (mode, ms, 2.0 * T * k * n / ms / 1e9, err)
         print(line)
