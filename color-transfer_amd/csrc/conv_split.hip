@@ -39,7 +39,13 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned int lds_addr) 
 }
 
 // wp : bf16 bit patterns [group][chunk16][tap][piece][m][lane = 32*khalf + cout%32][8 channels]   (host: pack_conv_weight_split)
-template <int KH, int KW, bool GEN>
+// F16: two fp16 pieces per operand and three v_mfma_f32_32x32x16_f16 per product instead of three bf16 pieces and six MFMAs (half
+// the matrix work, 2/3 of the LDS operand bytes; 2^-22 relative is dropped).  fp16 has five exponent bits: the weights carry one
+// power of two per layer (a.w_exp, host), every staged 16-channel input tile a RUNNING one per output tile (its maximum joins the
+// minimum exponent of the channels seen so far; the waves leave their maxima in LDS before the barrier that already separates "tile
+// consumed" from "next tile staged"); when it drops the accumulators are rescaled at the top of the stage.  Bias, pre-activation
+// addend, activation, skip and clamp all run in the epilogue on the unscaled value.
+template <int KH, int KW, bool GEN, bool F16>
 __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tiles_x, int tiles_y, int n_tiles) {
     constexpr int PADY = KH / 2, PADX = KW / 2;
     constexpr bool HALO = (KW > 1);
@@ -53,13 +59,15 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
     constexpr int NF = 192;                            // threads that fetch the input tile (waves 0..2; wave 3 streams weights)
     constexpr int PFE = (NE + NF - 1) / NF;
     constexpr int MT = 2, COUTP = 64, RPW = kSpTH / 4, TAPS = KH * KW;
+    constexpr int NP = F16 ? 2 : 3;                    // pieces per operand
     static_assert(NU <= NF, "tile geometry");
     extern __shared__ uint4 smem16[];
-    constexpr int WSLOT = 3 * MT * 64;                  // 16-byte entries of one tap's weight fragments
-    uint4 *tin = smem16;                                // [3][ROWS][2][TWP]
+    constexpr int WSLOT = NP * MT * 64;                 // 16-byte entries of one tap's weight fragments
+    uint4 *tin = smem16;                                // [NP][ROWS][2][TWP]
     constexpr int WRING = 4;                            // taps of weights resident in LDS
-    uint4 *wl = smem16 + 3 * PSZ;                       // [WRING][piece][m][lane]
-    float *stg = reinterpret_cast<float *>(smem16 + 3 * PSZ + WRING * WSLOT) + (threadIdx.x >> 6) * (32 * 32);
+    uint4 *wl = smem16 + NP * PSZ;                      // [WRING][piece][m][lane]
+    float *stg = reinterpret_cast<float *>(smem16 + NP * PSZ + WRING * WSLOT) + (threadIdx.x >> 6) * (32 * 32);
+    float *mxw = reinterpret_cast<float *>(smem16 + NP * PSZ + WRING * WSLOT) + 4 * (32 * 32);   // F16: the waves' tile maxima
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, hl = lane >> 5;
     const size_t plane = (size_t)a.H * a.W;
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
             }
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](float sc) {
         if (unit) {
             uint4 *dst = tin + (u_row * 2 + u_h) * TWP + COL0 + 4 * u_g;
 #pragma unroll
@@ -134,6 +142,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
                     const float4 v0 = pf4[2 * jp], v1 = pf4[2 * jp + 1];
                     const float x0 = px == 0 ? v0.x : px == 1 ? v0.y : px == 2 ? v0.z : v0.w;
                     const float x1 = px == 0 ? v1.x : px == 1 ? v1.y : px == 2 ? v1.z : v1.w;
+                    if constexpr (F16) {
+                        sp16_split2x2(x0 * sc, x1 * sc, hw[jp], lw[jp]);
+                        continue;
+                    }
 #ifdef CT_SPLIT_SCALAR
                     unsigned int h0, m0, l0, h1, m1, l1;
                     split3(x0, h0, m0, l0);
@@ -144,8 +156,12 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
 #endif
                 }
                 dst[px] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-                dst[PSZ + px] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
-                dst[2 * PSZ + px] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+                if constexpr (F16) {
+                    dst[PSZ + px] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+                } else {
+                    dst[PSZ + px] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
+                    dst[2 * PSZ + px] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+                }
             }
         }
         if constexpr (HALO) {
@@ -157,12 +173,19 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
                 const int yy = rem / HC, side = rem - yy * HC;
                 const int col = side < PADX ? COL0 - PADX + side : COL0 + kSpTW + side - PADX;
                 if (tid < NF && e < NE) {
-                    unsigned int h, m, l;
-                    split3(pfe[j], h, m, l);
                     const int idx = ((yy * 2 + (c >> 3)) * TWP + col) * 8 + (c & 7);
-                    t16[idx] = (unsigned short)h;
-                    t16[PSZ * 8 + idx] = (unsigned short)m;
-                    t16[2 * PSZ * 8 + idx] = (unsigned short)l;
+                    if constexpr (F16) {
+                        unsigned int hw, lw;
+                        sp16_split2x2(pfe[j] * sc, 0.f, hw, lw);
+                        t16[idx] = (unsigned short)hw;
+                        t16[PSZ * 8 + idx] = (unsigned short)lw;
+                    } else {
+                        unsigned int h, m, l;
+                        split3(pfe[j], h, m, l);
+                        t16[idx] = (unsigned short)h;
+                        t16[PSZ * 8 + idx] = (unsigned short)m;
+                        t16[2 * PSZ * 8 + idx] = (unsigned short)l;
+                    }
                 }
             }
         }
@@ -179,11 +202,11 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
     // issue cursor (taps are issued strictly in order, so no divisions): tap within the stage, chunk, group, ring slot
     int wi_tap = 0, wi_chunk = 0, wi_k = 0, wi_grp = (int)(tile_id(0) % a.groups), wi_slot = 0;
     auto w_issue = [&](int /*g*/) {
-        const uint4 *src = wp16 + ((((size_t)wi_grp * n_chunks + wi_chunk) * TAPS + wi_tap) * 3 * MT) * 64 + lane;
+        const uint4 *src = wp16 + ((((size_t)wi_grp * n_chunks + wi_chunk) * TAPS + wi_tap) * NP * MT) * 64 + lane;
         const unsigned int dst = wl_addr + (unsigned int)(wi_slot * WSLOT * 16);   // + 16 * lane is implied by the instruction
         if (wloader) {                                     // the cursor below advances in every wave: it stays scalar
 #pragma unroll
-            for (int f = 0; f < 3 * MT; ++f) glds16(src + f * 64, __builtin_amdgcn_readfirstlane(dst + f * 1024));
+            for (int f = 0; f < NP * MT; ++f) glds16(src + f * 64, __builtin_amdgcn_readfirstlane(dst + f * 1024));
         }
         wi_slot = (wi_slot + 1 == WRING) ? 0 : wi_slot + 1;
         if (++wi_tap == TAPS) {
@@ -198,8 +221,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
     // before the barrier that ends tap g: the fragments of tap g+1 have landed (loads of later taps may be in flight)
     auto w_landed = [&](int g) {
         const int ahead = n_gtaps - g - 2;                 // taps issued after tap g+1
-        if (ahead >= 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * 3 * MT));      // vmcnt(12)
-        else if (ahead == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (3 * MT));     // vmcnt(6)
+        if (ahead >= 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * NP * MT));     // vmcnt(12) (8 with two pieces)
+        else if (ahead == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (NP * MT));    // vmcnt(6) (4)
         else __builtin_amdgcn_s_waitcnt(0x0F70);                                 // vmcnt(0)
     };
 
@@ -221,7 +244,26 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
             for (int c = 0; c < half_tile_cycles; c += 64 * 64) __builtin_amdgcn_s_sleep(64);
         }
     }
-    const bool res_in_acc = (a.residual != nullptr) && (a.act == 0 || a.res_pre);
+    const bool res_in_acc = !F16 && (a.residual != nullptr) && (a.act == 0 || a.res_pre);
+    // F16: exponent of the tile in LDS / of the accumulators' domain; the maxima of the fetched tile (waves 0..2 fetch)
+    int e_stage = 100, e_cur = 100;
+    auto note_max = [&]() {
+        float mx = 0.f;
+        if (unit) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                mx = fmaxf(mx, fmaxf(fmaxf(fabsf(pf4[j].x), fabsf(pf4[j].y)), fmaxf(fabsf(pf4[j].z), fabsf(pf4[j].w))));
+        }
+        if constexpr (HALO) {
+#pragma unroll
+            for (int j = 0; j < PFE; ++j) mx = fmaxf(mx, fabsf(pfe[j]));
+        }
+        mx = sp16_wave_max(mx);
+        if (lane == 0) mxw[wave] = mx;
+    };
+    auto tile_exp = [&]() {
+        return __builtin_amdgcn_readfirstlane(sp16_scale_exp(fmaxf(fmaxf(mxw[0], mxw[1]), fmaxf(mxw[2], mxw[3])), 100));
+    };
     auto init_acc = [&](int k) {   // raw float4 rows of the skip tensor (or zeros); finish_acc() re-lays them out
         const int tg = tile_id(k), t = tg / a.groups, grp = tg - t * a.groups;
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
@@ -267,12 +309,37 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
     if (n_gtaps > 2) w_issue(2);
     if (wloader) w_landed(-1);
     fetch_tile(0);
-    init_acc(0);
-    store_tile();
+    if constexpr (F16) {
+        note_max();
+        __syncthreads();
+        e_stage = tile_exp();
+        store_tile(sp16_pow2i(e_stage));
+    } else {
+        init_acc(0);
+        store_tile(1.f);
+    }
     for (int stage = 0; stage < n_stages; ++stage) {
         const int k = stage / n_chunks, chunk = stage - k * n_chunks;
         const int grp = (int)(tile_id(k) % a.groups);
-        if (chunk == 0) {
+        if constexpr (F16) {
+            if (chunk == 0) {
+#pragma unroll
+                for (int q = 0; q < RPW; ++q)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[q][m][r] = 0.f;
+            } else if (e_stage != e_cur) {             // the running scale dropped: move the accumulators to the new domain
+                const float rs = __builtin_amdgcn_ldexpf(1.0f, e_stage - e_cur);
+#pragma unroll
+                for (int q = 0; q < RPW; ++q)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[q][m][r] *= rs;
+            }
+            e_cur = e_stage;
+        } else if (chunk == 0) {
             finish_acc();
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -290,21 +357,34 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
         CT_PHASE(1);
         const bool next_stage = (stage + 1 < n_stages);
         // B fragments of tap t: [q][piece]; read one tap ahead of the MFMAs that consume them
-        uint4 bc[RPW][3], bn[RPW][3];
-        auto read_b = [&](int tap, uint4 (&b)[RPW][3]) {
+        uint4 bc[RPW][NP], bn[RPW][NP];
+        auto read_b = [&](int tap, uint4 (&b)[RPW][NP]) {
             const int ky = tap / KW, kx = tap - ky * KW;
             const uint4 *bp = tin + ((wave * RPW + ky) * 2 + hl) * TWP + (COL0 - PADX) + kx + nl;
 #pragma unroll
             for (int q = 0; q < RPW; ++q)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) b[q][p] = bp[p * PSZ + q * 2 * TWP];
+                for (int p = 0; p < NP; ++p) b[q][p] = bp[p * PSZ + q * 2 * TWP];
         };
-        auto mfma6 = [&](const uint4 *ws, const uint4 (&b)[RPW][3]) {
-            uint4 w[3][MT];
+        auto mfma6 = [&](const uint4 *ws, const uint4 (&b)[RPW][NP]) {
+            uint4 w[NP][MT];
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NP; ++p)
 #pragma unroll
                 for (int m = 0; m < MT; ++m) w[p][m] = ws[(p * MT + m) * 64];
+            if constexpr (F16) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const f16x8s ah = __builtin_bit_cast(f16x8s, w[0][m]), al = __builtin_bit_cast(f16x8s, w[1][m]);
+#pragma unroll
+                    for (int q = 0; q < RPW; ++q) {        // small terms first
+                        const f16x8s bh = __builtin_bit_cast(f16x8s, b[q][0]), bl = __builtin_bit_cast(f16x8s, b[q][1]);
+                        acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[q][m], 0, 0, 0);
+                        acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[q][m], 0, 0, 0);
+                        acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[q][m], 0, 0, 0);
+                    }
+                }
+            } else {
             bf16x8 bf[RPW][3];
 #pragma unroll
             for (int q = 0; q < RPW; ++q)
@@ -324,6 +404,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
                     acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bf[q][0], acc[q][m], 0, 0, 0);
                 }
             }
+            }
         };
         read_b(0, bc);
 #pragma unroll
@@ -337,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
 #pragma unroll
             for (int q = 0; q < RPW; ++q)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) bc[q][p] = bn[q][p];
+                for (int p = 0; p < NP; ++p) bc[q][p] = bn[q][p];
             CT_PHASE(2);                                     // tap work: LDS operand reads + MFMAs (+ prefetch issue)
             if (wloader) { w_landed(g); CT_PHASE(6); }
             if (!last_tap) __syncthreads();                  // weight slot g%4 is free, slot (g+1)%4 is published
@@ -353,7 +434,75 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
             const int cout_g = a.cout - grp * COUTP;
             const bool full = (cout_g >= COUTP);
             const int x4 = tx * kSpTW + 4 * (lane & 7);
-            if (a.rows_channels > 0) {
+            if constexpr (F16) {
+                // unscale, bias, pre-activation addend, activation, skip, clamp -- all on the float32 value
+                const int un = -(e_cur + a.w_exp);
+                const float *__restrict__ bias_g = a.bias + grp * COUTP;
+                if (a.rows_channels > 0) {
+                    float *__restrict__ orow = a.out + (size_t)n * plane * a.rows_channels + a.rows_c0 + grp * COUTP;
+                    const int x = tx * kSpTW + nl;
+#pragma unroll
+                    for (int q = 0; q < RPW; ++q) {
+                        const int y = ty * kSpTH + wave * RPW + q;
+                        if (y < a.H && x < a.W) {
+                            float *__restrict__ op = orow + (size_t)(y * a.W + x) * a.rows_channels;
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const int co = m * 32 + 8 * j + 4 * hl;
+                                    const float4 b4 = *reinterpret_cast<const float4 *>(bias_g + co);
+                                    float4 v = make_float4(__builtin_amdgcn_ldexpf(acc[q][m][4 * j], un) + b4.x,
+                                                           __builtin_amdgcn_ldexpf(acc[q][m][4 * j + 1], un) + b4.y,
+                                                           __builtin_amdgcn_ldexpf(acc[q][m][4 * j + 2], un) + b4.z,
+                                                           __builtin_amdgcn_ldexpf(acc[q][m][4 * j + 3], un) + b4.w);
+                                    if (a.act) {
+                                        v.x = split_act<GEN>(v.x, a.act); v.y = split_act<GEN>(v.y, a.act);
+                                        v.z = split_act<GEN>(v.z, a.act); v.w = split_act<GEN>(v.w, a.act);
+                                    }
+                                    if (full || co < cout_g) *reinterpret_cast<float4 *>(op + co) = v;
+                                }
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < RPW; ++q) {
+                        const int y = ty * kSpTH + wave * RPW + q;
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int ch = (r & 3) + 8 * (r >> 2) + 4 * hl;
+                                stg[ch * 32 + nl] = __builtin_amdgcn_ldexpf(acc[q][m][r], un) + bias_g[m * 32 + ch];
+                            }
+                            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int co = m * 32 + (lane >> 3) + 8 * j;
+                                float4 v = *reinterpret_cast<const float4 *>(stg + ((lane >> 3) + 8 * j) * 32 + 4 * (lane & 7));
+                                if (y < a.H && x4 < a.W && (full || co < cout_g)) {
+                                    const unsigned int o = (unsigned int)co * uplane + (unsigned int)(y * a.W + x4);
+                                    float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+                                    if (res) rr = *reinterpret_cast<const float4 *>(res + o);
+                                    if (a.res_pre) { v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+                                    if (a.act) {
+                                        v.x = split_act<GEN>(v.x, a.act); v.y = split_act<GEN>(v.y, a.act);
+                                        v.z = split_act<GEN>(v.z, a.act); v.w = split_act<GEN>(v.w, a.act);
+                                    }
+                                    if (!a.res_pre) { v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+                                    if (a.clamp) {
+                                        v.x = fminf(fmaxf(v.x, 0.f), 1.f); v.y = fminf(fmaxf(v.y, 0.f), 1.f);
+                                        v.z = fminf(fmaxf(v.z, 0.f), 1.f); v.w = fminf(fmaxf(v.w, 0.f), 1.f);
+                                    }
+                                    *reinterpret_cast<float4 *>(out + o) = v;
+                                }
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
+                }
+            } else if (a.rows_channels > 0) {
                 // token-rows output [N*H, W, rows_channels]: the lane's four consecutive channels of each 8-group are one 16-byte
                 // store at its pixel (no staging); the attention kernels read this layout, so the NCHW tensor and its transpose
                 // never exist
@@ -413,12 +562,21 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
                     __builtin_amdgcn_wave_barrier();
                 }
             }
-            if (next_stage) init_acc(k + 1);
+            if constexpr (!F16) { if (next_stage) init_acc(k + 1); }
         }
+        if constexpr (F16) { if (next_stage) note_max(); }   // waits for the tile loads issued at tap 0
         CT_PHASE(3);                       // epilogue
-        __syncthreads();                   // every wave is done reading this stage's tile
+        __syncthreads();                   // every wave is done reading this stage's tile (F16: the next tile's maxima are visible)
         CT_PHASE(4);
-        if (next_stage) store_tile();
+        if constexpr (F16) {
+            if (next_stage) {
+                const int et = tile_exp();
+                e_stage = (chunk + 1 == n_chunks) ? et : min(e_stage, et);     // a new output tile starts its own running scale
+                store_tile(sp16_pow2i(e_stage));
+            }
+        } else {
+            if (next_stage) store_tile(1.f);
+        }
     }
 #ifdef CT_CONV_PROFILE
     CT_PHASE(0);
@@ -429,16 +587,16 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
 #endif
 }
 
-template <int KH, int KW, bool GEN>
+template <int KH, int KW, bool GEN, bool F16 = false>
 static int launch_split(const ConvArgs &a, int N, hipStream_t s) {
-    constexpr int ROWS = kSpTH + KH - 1, TWP = (KW > 1) ? kSpTW + 8 : kSpTW;
-    const size_t lds = (size_t)3 * ROWS * 2 * TWP * 16 + (size_t)4 * 3 * 2 * 64 * 16 + (size_t)4 * 32 * 32 * sizeof(float);
+    constexpr int ROWS = kSpTH + KH - 1, TWP = (KW > 1) ? kSpTW + 8 : kSpTW, NP = F16 ? 2 : 3;
+    const size_t lds = (size_t)NP * ROWS * 2 * TWP * 16 + (size_t)4 * NP * 2 * 64 * 16 + (size_t)4 * 32 * 32 * sizeof(float) + 16;
     const int tiles_x = (a.W + kSpTW - 1) / kSpTW, tiles_y = (a.H + kSpTH - 1) / kSpTH;
     const long long n_tiles = (long long)tiles_x * tiles_y * N * a.groups;
     if (n_tiles > 0x7fffffffLL) return CT_E_BADARG;
     static const int wgs_per_cu = [] { const char *e = getenv("CT_HIP_SPLIT_WGS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 2; }();
     const int grid = n_tiles < wgs_per_cu * kSpCUs ? (int)n_tiles : wgs_per_cu * kSpCUs;
-    hipLaunchKernelGGL((conv_split_kernel<KH, KW, GEN>), dim3(grid), dim3(256), lds, s, a, tiles_x, tiles_y, (int)n_tiles);
+    hipLaunchKernelGGL((conv_split_kernel<KH, KW, GEN, F16>), dim3(grid), dim3(256), lds, s, a, tiles_x, tiles_y, (int)n_tiles);
     CT_CHECK_LAUNCH();
     return CT_OK;
 }
@@ -457,6 +615,13 @@ int conv_split(const ConvArgs &a, int N, int kh, int kw, bool gen, hipStream_t s
     if (kh == 3 && kw == 3 && a.rows_channels == 0 && !a.res_pre) {
         const int rc = conv_ws(a, N, gen, s);
         if (rc != 1) return rc;
+    }
+    if (a.f16) {
+        if (kh == 3 && kw == 3) return launch_split<3, 3, true, true>(a, N, s);
+        if (kh == 1 && kw == 1) return launch_split<1, 1, true, true>(a, N, s);
+        if (kh == 1 && kw == 5) return launch_split<1, 5, true, true>(a, N, s);
+        if (kh == 5 && kw == 1) return launch_split<5, 1, true, true>(a, N, s);
+        return 1;
     }
     if (gen) {
         if (kh == 3 && kw == 3) return launch_split<3, 3, true>(a, N, s);
@@ -477,7 +642,7 @@ extern "C" {
 int ct_conv2d_split_f32(const float *in, const float *in2, int cin1, const float *in3, int cin2, const void *wp_split, const float *bias,
                         const float *residual, float *out, int n, int cin, int cout, int h, int w, int kh, int kw, long long in_bstride,
                         long long in2_bstride, long long in3_bstride, long long out_bstride, long long res_bstride, int act, int clamp,
-                        int res_pre_act, void *stream) {
+                        int res_pre_act, int f16, int w_exp, void *stream) {
     if (!in || !wp_split || !bias || !out || n < 0 || cin < 1 || cout < 1 || h < 0 || w < 0 || act < 0 || act > 5) return CT_E_BADARG;
     if (in2 && (cin1 < 16 || cin1 >= cin || (cin1 % 16))) return CT_E_BADARG;
     if (in3 && (!in2 || cin2 <= cin1 || cin2 >= cin || (cin2 % 16))) return CT_E_BADARG;
@@ -490,12 +655,14 @@ int ct_conv2d_split_f32(const float *in, const float *in2, int cin1, const float
     a.in_bstride = in_bstride; a.out_bstride = out_bstride; a.res_bstride = res_bstride;
     a.act = act; a.clamp = clamp; a.groups = (cout + 63) / 64; a.prof = nullptr;
     a.res_pre = (residual && res_pre_act) ? 1 : 0;
+    a.f16 = f16 ? 1 : 0; a.w_exp = f16 ? w_exp : 0;
     const int rc = ct::conv_split(a, n, kh, kw, true, (hipStream_t)stream);
     return rc == 1 ? CT_E_BADARG : rc;
 }
 
 int ct_conv2d_split_rows_f32(const float *in, const void *wp_split, const float *bias, float *out_rows, int n, int cin, int cout, int h,
-                             int w, int kh, int kw, long long in_bstride, int rows_channels, int rows_c0, int act, void *stream) {
+                             int w, int kh, int kw, long long in_bstride, int rows_channels, int rows_c0, int act, int f16, int w_exp,
+                             void *stream) {
     if (!in || !wp_split || !bias || !out_rows || n < 0 || cin < 1 || cout < 1 || h < 0 || w < 0 || act < 0 || act > 5) return CT_E_BADARG;
     if (rows_channels < 4 || rows_c0 < 0) return CT_E_BADARG;
     if (n == 0 || h == 0 || w == 0) return CT_OK;
@@ -506,6 +673,7 @@ int ct_conv2d_split_rows_f32(const float *in, const void *wp_split, const float 
     a.in_bstride = in_bstride; a.out_bstride = 0; a.res_bstride = 0;
     a.act = act; a.clamp = 0; a.groups = (cout + 63) / 64; a.prof = nullptr;
     a.rows_channels = rows_channels; a.rows_c0 = rows_c0;
+    a.f16 = f16 ? 1 : 0; a.w_exp = f16 ? w_exp : 0;
     const int rc = ct::conv_split(a, n, kh, kw, true, (hipStream_t)stream);
     return rc == 1 ? CT_E_BADARG : rc;
 }

@@ -48,4 +48,35 @@ __device__ __forceinline__ void split3x2(float x0, float x1, unsigned int &hw, u
     lw = pack_bf16(r0 - __uint_as_float(mw << 16), r1 - __uint_as_float(mw & 0xffff0000u));
 }
 
+// ---- two fp16 pieces (hi + lo, 11 + 11 mantissa bits) with power-of-two scales: conv_split.hip's F16 form ----
+typedef _Float16 f16x8s __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2s __attribute__((ext_vector_type(2)));
+// opaque to the compiler (it otherwise re-derives each half with v_fma_mixlo_f16 when the halves are converted back)
+__device__ __forceinline__ unsigned int sp16_cvt_pk(float a, float b) {
+    unsigned int r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void sp16_split2x2(float x0, float x1, unsigned int &hw, unsigned int &lw) {
+    hw = sp16_cvt_pk(x0, x1);
+    const f16x2s h = __builtin_bit_cast(f16x2s, hw);
+    lw = sp16_cvt_pk(x0 - (float)h.x, x1 - (float)h.y);
+}
+// exponent e with 2^e * mx in [2^11, 2^12); `none` for mx == 0 / denormal; 0 for inf / NaN (they propagate)
+__device__ __forceinline__ int sp16_scale_exp(float mx, int none) {
+    const int fld = (int)(__float_as_uint(mx) >> 23);
+    const int ex = fld == 0 ? none : fld == 255 ? 0 : 138 - fld;
+    return min(max(ex, -100), 100);
+}
+__device__ __forceinline__ float sp16_pow2i(int e) { return __uint_as_float((unsigned int)(127 + e) << 23); }   // |e| <= 126
+// max over the wave of a non-negative float; every lane returns it
+__device__ __forceinline__ float sp16_wave_max(float v) {
+    int x = __float_as_int(v);
+#define CT_DPP_MAX(ctrl, rmask) x = max(x, __builtin_amdgcn_update_dpp(0, x, ctrl, rmask, 0xf, false))
+    CT_DPP_MAX(0x111, 0xf); CT_DPP_MAX(0x112, 0xf); CT_DPP_MAX(0x114, 0xf); CT_DPP_MAX(0x118, 0xf);
+    CT_DPP_MAX(0x142, 0xa); CT_DPP_MAX(0x143, 0xc);
+#undef CT_DPP_MAX
+    return __int_as_float(__builtin_amdgcn_readlane(x, 63));
+}
+
 }  // namespace ct

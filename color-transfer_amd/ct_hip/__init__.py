@@ -523,7 +523,7 @@ SIGNATURES.update({
                                _c_ll, _c_int, _c_int, _c_p]),
     "ct_pam_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
     "ct_conv2d_split_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int,
-                                     _c_int, _c_int, _c_ll, _c_ll, _c_ll, _c_ll, _c_ll, _c_int, _c_int, _c_int, _c_p]),
+                                     _c_int, _c_int, _c_ll, _c_ll, _c_ll, _c_ll, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "ct_pam_attend_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "ct_pam_valid_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_sz, _c_p]),
 })
@@ -534,8 +534,9 @@ SIGNATURES.update({
 #          accuracy, 2.67x the matrix rate).  "exact": v_mfma_f32_32x32x2_f32, bitwise an fmaf chain (csrc/cnn.hip).
 # Geometries the split kernel does not cover (stride 2, 7x7, W % 4 != 0, unaligned views) always run "exact".
 _conv_mode = os.environ.get("CT_HIP_CONV", "split")
-# split mode, 3x3 convolutions with 32 < cin <= 64 (the ResB convs): two fp16 pieces / three MFMAs per product on the
-# weight-stationary kernel (csrc/conv_ws.hip) instead of three bf16 pieces / six MFMAs; CT_HIP_CONV_WS16=0 switches it off
+# split mode: two fp16 pieces / three MFMAs per product (power-of-two scales per layer and per staged tile / row) instead of three
+# bf16 pieces / six MFMAs, in the weight-stationary kernel (csrc/conv_ws.hip) and the tile kernel (csrc/conv_split.hip);
+# CT_HIP_CONV_WS16=0 switches back to the bf16 form
 _ws16 = os.environ.get("CT_HIP_CONV_WS16", "1") != "0"
 
 
@@ -607,7 +608,7 @@ def _ws16_ok(x, split, kh, kw):
 def _split_operands(weight, bias):
     """(bf16 pieces, padded bias, fp16 image or None): what travels with a packed convolution weight as `_ct_split`"""
     cout, cin, kh, kw = weight.shape
-    w16 = pack_conv_weight_split16(weight) if (kh, kw) == (3, 3) and 32 < cin <= 64 else None
+    w16 = pack_conv_weight_split16(weight) if (kh, kw) in ((3, 3), (1, 1), (1, 5), (5, 1)) else None
     return pack_conv_weight_split(weight, bias) + (w16,)
 
 
@@ -624,6 +625,9 @@ def _split_ok(x, out, residual, kh, kw, stride, ph, pw):
 
 def _conv_split(x, split, cout, kh, kw, act, residual, clamp, out, x2=None, x3=None, res_pre=False):
     ws, b64 = split[0], split[1]
+    f16, w_exp = 0, 0
+    if _ws16 and len(split) > 2 and split[2] is not None:      # two fp16 pieces (default): the fp16 image replaces the bf16 one
+        (ws, w_exp), f16 = split[2], 1
     n, cin1, h, w = x.shape
     cin2 = cin1 + (x2.shape[1] if x2 is not None else 0)
     cin = cin2 + (x3.shape[1] if x3 is not None else 0)
@@ -636,7 +640,7 @@ def _conv_split(x, split, cout, kh, kw, act, residual, clamp, out, x2=None, x3=N
     check(lib().ct_conv2d_split_f32(_ptr(x), _opt(x2), cin1, _opt(x3), cin2, _ptr(ws), _ptr(b64), _opt(residual), _ptr(out), n, cin,
                                     cout, h, w, kh, kw, _nchw_bstride(x), _nchw_bstride(x2) if x2 is not None else 0,
                                     _nchw_bstride(x3) if x3 is not None else 0, _nchw_bstride(out), rs, int(act), int(bool(clamp)),
-                                    int(bool(res_pre)), _stream()))
+                                    int(bool(res_pre)), f16, int(w_exp), _stream()))
     return out
 
 
@@ -711,8 +715,11 @@ def conv2d_rows(x, wp, bias, cout, ksize, act=0, out=None, c0=0, channels=None):
     if (out.shape != (n * h, w, channels) or not out.is_contiguous() or out.dtype != torch.float32 or out.device != x.device or
             channels % 4 or c0 % 4 or cout % 4 or c0 + cout > channels):
         raise CtHipError("conv2d_rows: out must be a contiguous float32 [N*H, W, channels] tensor, channels / c0 / cout multiples of 4")
-    check(lib().ct_conv2d_split_rows_f32(_ptr(x), _ptr(split[0]), _ptr(split[1]), _ptr(out), n, cin, cout, h, w, ksize, ksize,
-                                         _nchw_bstride(x), channels, int(c0), int(act), _stream()))
+    ws, f16, w_exp = split[0], 0, 0
+    if _ws16 and len(split) > 2 and split[2] is not None:
+        (ws, w_exp), f16 = split[2], 1
+    check(lib().ct_conv2d_split_rows_f32(_ptr(x), _ptr(ws), _ptr(split[1]), _ptr(out), n, cin, cout, h, w, ksize, ksize,
+                                         _nchw_bstride(x), channels, int(c0), int(act), f16, int(w_exp), _stream()))
     return out
 
 
@@ -757,7 +764,7 @@ def pam_valid(q, k, want_att=False):
 _c_f = ctypes.c_float
 SIGNATURES.update({
     "ct_gconv2d_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 10 + [_c_ll, _c_ll, _c_int, _c_p]),
-    "ct_conv2d_split_rows_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 7 + [_c_ll, _c_int, _c_int, _c_int, _c_p]),
+    "ct_conv2d_split_rows_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 7 + [_c_ll, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "ct_conv3x3_ws16_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p] + [_c_int] * 5 + [_c_ll, _c_ll, _c_ll, _c_int, _c_int, _c_p]),
     "ct_instance_norm_workspace_bytes": (ctypes.c_size_t, [_c_int]),
     "ct_instance_norm_f32": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_f, _c_int, _c_p, ctypes.c_size_t, _c_p]),

@@ -33,7 +33,7 @@ extern "C" {
 #define CT_E_WORKSPACE (-2)  /* workspace too small / misaligned */
 #define CT_E_ALIGN (-3)      /* image base not aligned to its element size */
 
-/* bumped whenever an entry point changes its argument list (2: ct_attention_tokens_f32 gained kv_shift; 3: round 3; 4: ct_conv2d_split_rows_f32, res_pre_act, ct_linear_ws16_f32, layernorm partials);
+/* bumped whenever an entry point changes its argument list (2: ct_attention_tokens_f32 gained kv_shift; 3: round 3; 4: ct_conv2d_split_rows_f32, res_pre_act, ct_linear_ws16_f32, layernorm partials, f16 form of ct_conv2d_split*);
  * the ctypes binding refuses a library whose ct_abi_version() differs */
 #define CT_ABI_VERSION 4
 
@@ -239,12 +239,15 @@ int ct_conv2d_f32(const float *in, const float *wp, const float *bias, const flo
  * (reg_refine.py:43,72,75: the GRU's hx / [r*h, x] and the motion encoder's [cor, flo]).
  * in3 != NULL (needs in2): channels [cin2, cin) come from in3 (cin2 % 16 == 0, cin1 < cin2 < cin): DCMCS3DI's
  * transfer[0] reads cat([fea_left, fea_warped, valid_left]) (methods/dcmcs3di.py:59,47) from its three tensors.
+ * f16 != 0: wp_split is the TWO-piece fp16 image of weight * 2^w_exp instead (ct_hip.pack_conv_weight_split16: same index order
+ * with [piece hi,lo]; three v_mfma_f32_32x32x16_f16 per product, 2^-22 relative dropped; every staged 16-channel input tile
+ * carries a running power-of-two scale per output tile, so any finite float32 input is in range) -- half the matrix work.
  * residual: added after the activation (ResB skip), or -- res_pre_act != 0 -- BEFORE it: a pre-computed partial convolution
  * (the SepConvGRU's loop-invariant `inp` channels, reg_refine.py:25-55: conv(cat([h, inp, motion])) = conv_inp(inp) + conv(rest)). */
 int ct_conv2d_split_f32(const float *in, const float *in2, int cin1, const float *in3, int cin2, const void *wp_split,
                         const float *bias, const float *residual, float *out, int n, int cin, int cout, int h, int w, int kh,
                         int kw, long long in_bstride, long long in2_bstride, long long in3_bstride, long long out_bstride,
-                        long long res_bstride, int act, int clamp, int res_pre_act, void *stream);
+                        long long res_bstride, int act, int clamp, int res_pre_act, int f16, int w_exp, void *stream);
 
 /* ct_conv2d_split_f32 of one input tensor with the result stored as TOKEN ROWS: out_rows[(n*h + y)*w + x][rows_c0 + co] of a
  * [n*h, w, rows_channels] tensor (rows_channels, rows_c0, cout multiples of 4; rows_c0 + cout <= rows_channels).  The query / key /
@@ -252,7 +255,7 @@ int ct_conv2d_split_f32(const float *in, const float *in2, int cin1, const float
  * ct_attention_rows64_f32 reads, so their NCHW tensors and the transposes never exist.  No residual / clamp in this form. */
 int ct_conv2d_split_rows_f32(const float *in, const void *wp_split, const float *bias, float *out_rows, int n, int cin, int cout,
                              int h, int w, int kh, int kw, long long in_bstride, int rows_channels, int rows_c0, int act,
-                             void *stream);
+                             int f16, int w_exp, void *stream);
 
 /* The ResB convolutions (3x3, stride 1, padding 1, 32 < cin <= 64; reference pasmnet/backbone.py:8-15, unimatch/backbone.py
  * residual blocks) on the weight-stationary kernel of csrc/conv_ws.hip with float32 operands as TWO fp16 pieces and three

@@ -164,9 +164,9 @@ def test_conv_rows_argument_checks_and_fallback(hip):
     finally:
         hip.set_conv_mode("split")
     lib, p, null = hip.lib(), x.data_ptr(), None
-    assert lib.ct_conv2d_split_rows_f32(p, p, p, p, 1, 64, 64, 8, 32, 1, 1, 64 * 8 * 32, 66, 0, 0, null) == -1
-    assert lib.ct_conv2d_split_rows_f32(p, p, p, p, 1, 64, 64, 8, 32, 1, 1, 64 * 8 * 32, 64, 4, 0, null) == -1
-    assert lib.ct_conv2d_split_rows_f32(p, p, p, p, 0, 64, 64, 8, 32, 1, 1, 64 * 8 * 32, 64, 0, 0, null) == 0
+    assert lib.ct_conv2d_split_rows_f32(p, p, p, p, 1, 64, 64, 8, 32, 1, 1, 64 * 8 * 32, 66, 0, 0, 0, 0, null) == -1
+    assert lib.ct_conv2d_split_rows_f32(p, p, p, p, 1, 64, 64, 8, 32, 1, 1, 64 * 8 * 32, 64, 4, 0, 0, 0, null) == -1
+    assert lib.ct_conv2d_split_rows_f32(p, p, p, p, 0, 64, 64, 8, 32, 1, 1, 64 * 8 * 32, 64, 0, 0, 0, 0, null) == 0
 
 
 def test_dcmcs3di_rows_path_equals_transposed_path(hip):
