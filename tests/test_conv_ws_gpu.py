@@ -188,3 +188,38 @@ def test_dcmcs3di_rows_path_equals_transposed_path(hip):
     fw, wrgb, valid, colsum = hip.pam_streaming(q[:1].contiguous(), k[1:].contiguous(), v, right, q[1:].contiguous(), k[:1].contiguous())
     assert torch.equal(parts["fea_warped"], fw) and torch.equal(parts["warped_rgb"], wrgb)
     assert torch.equal(parts["colsum_left"], colsum) and torch.equal(parts["valid_left"], valid)
+
+
+@pytest.mark.parametrize("kh,kw", [(3, 3), (1, 5), (5, 1), (1, 1)])
+def test_conv_split16_wide_dynamic_range(hip, kh, kw):
+    """the tile kernel in its two-piece fp16 form (csrc/conv_split.hip, F16): the running power-of-two scale of the staged
+    16-channel input tiles -- channel blocks of very different magnitude in either order (the accumulators are rescaled when the
+    scale drops in the middle of the contraction), all-zero blocks, image regions of different magnitude, a tiny per-layer weight
+    scale; pre-activation addend, activation and skip on the unscaled value"""
+    n, cin, cout, h, w = 2, 160, 96, 19, 72
+    x = rnd(n, cin, h, w)
+    x[:, 16:32] *= 1e-6
+    x[:, 48:64] = 0.0
+    x[0, 64:96] *= 3e4                    # large channels in the middle: the scale drops at chunk 4
+    x[1, :16] *= 1e5                      # ... or at once
+    x[:, :, :, 40:] *= 1e-3               # the right tiles live at another magnitude
+    wt, b = rnd(cout, cin, kh, kw) / (cin * kh * kw) ** 0.5 * 1e-4, rnd(cout) * 1e-3
+    res, add = rnd(n, cout, h, w), rnd(n, cout, h, w) * 1e-2
+    wp, bp = hip.pack_gconv_weight(wt.cuda(), b.cuda())
+    pad = (kh // 2, kw // 2)
+    lin = F.conv2d(x.double(), wt.double(), b.double(), padding=pad)
+    bound = F.conv2d(x.double().abs(), wt.double().abs(), None, padding=pad) + 1e-300       # sum |x||w|
+    # the staged tile is 16 channels x (8 + kh - 1) rows x (32 + 8) columns: a value keeps 2^-36 of its tile's maximum
+    floor = 2.0 ** -34 * F.max_pool2d(x.abs().amax(dim=1, keepdim=True), (2 * 12 + 1, 2 * 44 + 1), 1, (12, 44)).double() * wt.abs().sum().item() / cout
+    got = hip.gconv2d(x.cuda(), wp, bp, cout, (kh, kw), 1, pad).double().cpu()
+    assert ((got - lin).abs() / (1e-6 * bound + floor + 1e-7 * b.abs().max().item())).max().item() < 1.0
+    got = hip.gconv2d(x.cuda(), wp, bp, cout, (kh, kw), 1, pad, act=3, addend=add.cuda()).double().cpu()      # sigmoid(conv + addend)
+    assert (got - torch.sigmoid(lin + add.double())).abs().max().item() < 2e-6
+    got = hip.gconv2d(x.cuda(), wp, bp, cout, (kh, kw), 1, pad, residual=res.cuda()).double().cpu()
+    assert ((got - (lin + res.double())).abs() / (1e-6 * bound + floor + 3e-7 * (1 + res.abs().double()))).max().item() < 1.0
+    hip.set_conv_ws16(False)              # the three-piece bf16 form computes the same layer
+    try:
+        old = hip.gconv2d(x.cuda(), wp, bp, cout, (kh, kw), 1, pad).double().cpu()
+    finally:
+        hip.set_conv_ws16(True)
+    assert ((old - lin).abs() / (1e-6 * bound + 1e-7 * b.abs().max().item())).max().item() < 1.0
