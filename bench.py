@@ -367,13 +367,14 @@ def main():
             # 0, reference in every histogram, apply 0 input) = 8 float32 planes of 24.9 MB + 10 float64 planes of 49.8 MB
             extra["idt_frac_hbm_peak_bytes_moved"] = (8 * 4 + 10 * 8) * 3 * H * W * idt / HBM_PEAK
             del idt_out
-            # configs[2]: DCMCS3DI forward, random init, 512x512.  The convolutions run float32 operands as three bf16
-            # pieces with six bf16 MFMAs per product (float32-grade accuracy, csrc/conv_split.hip); rates are quoted in
-            # algorithmic (float32) FLOPs against the FP32 matrix peak, and x6 against the dense bf16 peak.
+            # configs[2]: DCMCS3DI forward, random init, 512x512.  The convolutions and the attention run float32 operands as two
+            # fp16 pieces with three MFMAs per product (float32-grade accuracy, csrc/conv_ws.hip, conv_split.hip, attention16.hip);
+            # rates are quoted in algorithmic (float32) FLOPs, and x3 (MFMA flops issued) against the dense 16-bit peak.
             ws16 = ct_hip.conv_ws16() and ct_hip.conv_mode() == "split"
             extra["cnn_conv_arithmetic"] = (
-                "float32 operands, float32 accumulate; ResB convs (3x3, cin 64): 2 fp16 pieces, 3 fp16 MFMAs per product, weights "
-                "stationary in registers (conv_ws); other convs / linears / attention: 3 bf16 pieces, 6 bf16 MFMAs per product"
+                "float32 operands, float32 accumulate; convolutions (weight-stationary conv_ws for the ResB convs, tile kernel "
+                "conv_split elsewhere), attention (attention16) and the FFN linears (linear_ws16): 2 fp16 pieces with power-of-two "
+                "scales, 3 fp16 MFMAs per product; the 128 -> 128 token projections: 3 bf16 pieces, 6 MFMAs per product"
                 if ws16 else "f32 as 3 bf16 pieces, 6 bf16 MFMAs per product, f32 accumulate (%s mode)" % ct_hip.conv_mode())
             mfma_per_flop = 3.0 if ws16 else 6.0       # MFMA flops issued per algorithmic (float32) flop in the dominant convs
             from methods.dcmcs3di import DCMCS3DI
@@ -398,8 +399,8 @@ def main():
             busy = json.load(open(pm)) if os.path.exists(pm) else {}
             kdom = [v for k, v in busy.items() if "conv_ws_kernel" in k]
             roof_cnn = {"bound": "mfma", "workload": "dcmcs3di forward, random init, 1 pair of 1920x1080, float32 I/O",
-                        "dtype": "16-bit MFMA pipe (float32 operands as 2 fp16 pieces / 3 MFMAs per product in the ResB convs, 3 bf16 "
-                                 "pieces / 6 MFMAs elsewhere), f32 accumulate",
+                        "dtype": "16-bit MFMA pipe (float32 operands as 2 fp16 pieces / 3 MFMAs per product in the convolutions and the "
+                                 "attention), f32 accumulate",
                         "achieved": mfma_per_flop * flop2 * dc2 / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                         "frac_flops": mfma_per_flop * flop2 * dc2 / 2.5e15,
                         "frac": busy.get("_all_kernels", {}).get("mfma_busy_frac_time_weighted"),
@@ -420,10 +421,15 @@ def main():
             size = DMSCT.derive_matcher_inference_size(a960.shape)
             gr = rate(lambda: gm(a960, b960, inference_size=size, pred_bidir_flow=True, fwd_bwd_consistency_check=True), n=3)
             extra["gmflow_960x540_pairs_per_s_f32"] = gr
+            # the reference's algorithmic FLOPs per pair; 0.376e12 of them (the SepConvGRU's loop-invariant input blocks)
+            # are convolved once per forward instead of once per refinement iteration, so this is a throughput equivalent
             extra["gmflow_960x540_tflops_f32_equivalent"] = 3.58357106688e12 * gr / 1e12
             pm = os.path.join(ROOT, "profiles", "r03_gmflow_960x540_mfma_pmc.json")
             if os.path.exists(pm):
                 extra["gmflow_960x540_mfma_busy_time_weighted"] = json.load(open(pm)).get("_all_kernels", {}).get("mfma_busy_frac_time_weighted")
+                extra["gmflow_960x540_mfma_busy_note"] = ("MFMA-busy is not comparable across arithmetic forms: the fp16 two-piece kernels issue "
+                                                          "half the MFMA cycles per product of the bf16 three-piece ones they replaced "
+                                                          "(33 -> 24 ms per pair at 0.245 -> 0.22 busy)")
             # configs[3] whole: DMSCT.forward (matcher + EfficientNet-B2 encoder on both views + fusion + U-Net decoder + head), random init
             dm = DMSCT().to(device).eval()
             dm.matcher = gm

@@ -342,7 +342,11 @@ int ct_layernorm128_f32(const float *x, const float *gamma, const float *beta, c
  *   workgroups cannot fill the 256 CUs.
  *   kv_shift (rowmap launches; else 0): the keys / values of a token are read kv_shift rows further (mod batch*len) than
  *   its query -- the cross attention of transformer.py:281-287 attends every image to the other half of the batch
- *   (kv_shift = batch*len/2) without materialising torch.cat(chunk(2)[::-1]).                                       */
+ *   (kv_shift = batch*len/2) without materialising torch.cat(chunk(2)[::-1]).
+ *   Arithmetic (this entry and the two ct_attention_*64_f32 below): both products on the 16-bit matrix pipe with float32
+ *   operands as two fp16 pieces and power-of-two scales per query row / staged key tile / running per value tile
+ *   (csrc/attention16.hip; 2^-22 relative dropped; a probability below 2^-29 of its row's maximum keeps an absolute error of
+ *   2^-40 of it); env CT_HIP_ATT16=0 selects the three-piece bf16 kernels of csrc/gmflow.hip.                      */
 size_t ct_attention_workspace_bytes(int batch, int len, int cv, int nsplit);
 int ct_attention_tokens_f32(const float *q, const float *k, const float *v, const int *region, const int *rowmap,
                             float *out, int batch, int len, int cv, float scale, int nsplit, float *ws,
