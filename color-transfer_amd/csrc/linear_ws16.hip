@@ -28,7 +28,9 @@ typedef float f32x16w __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8w __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2w __attribute__((ext_vector_type(2)));
 
-constexpr int kW16Img = 2 * 16 * 2 * 128;       // uint4 entries of one slice image: [piece][k step][lane half][feature] x 8 channels
+// uint4 entries of one slice image: [piece][k step][lane half][feature] x 8 channels; NCH = 16-channel chunks per lane half
+// (8: slices of 256 input channels; 4: slices of 128 -- the q / k / v / merge projections, several of them in one launch)
+constexpr int w16_img(int NCH) { return 2 * (2 * NCH) * 2 * 128; }
 
 __device__ __forceinline__ unsigned int cvt_pk_f16w(float a, float b) {
     unsigned int r;
@@ -63,7 +65,7 @@ struct Ws16Args {
     const float *xa, *xb;          // token rows read by lane half 0 / 1 (slice 0): 128 channels each
     long long lda, ldb;            // row strides (floats)
     long long x_slice;             // + slice * x_slice floats on both (K slices), 0 for N slices
-    const uint4 *wp;               // [slice][kW16Img]
+    const uint4 *wp;               // [slice][w16_img(NCH)]
     int w_exp;
     const float *bias;             // nullable; N slices: bias + slice * 128; K slices: added by slice 0 only
     float *out;
@@ -71,19 +73,23 @@ struct Ws16Args {
     long long out_slice;           // + slice * out_slice floats (N slices: 128 columns; K slices: T * 128)
     long long T;
     int n_tiles;                   // 32-token tiles
-    int S;                         // slices (divides 32)
+    int S;                         // slices (1, 2, 3, 4, 8, 16, 32: floor(32 / S) token groups per XCD)
     int kslices;                   // 1 = K slices (partials), 0 = N slices
     int act;                       // 0 none, 6 GELU
 };
 
+template <int NCH>
 __global__ __launch_bounds__(512, 1) void linear_ws16_kernel(Ws16Args a) {
+    constexpr int kW16Img = w16_img(NCH), KS = 2 * NCH;
     extern __shared__ uint4 Ws[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, hl = lane >> 5;
     // workgroup b sits on XCD b % 8: the S slices of one token group share an XCD (and, N slices, their tokens through its L2)
     const int xcd = blockIdx.x & 7, m = blockIdx.x >> 3;
     const int per_xcd = gridDim.x >> 3;
+    const int gpx = per_xcd / a.S;                 // token groups per XCD (S = 3: two workgroups per XCD stay idle)
+    if (m >= gpx * a.S) return;
     const int slice = m % a.S;
-    const int group = m / a.S + (per_xcd / a.S) * xcd, n_groups = (per_xcd / a.S) * 8;
+    const int group = m / a.S + gpx * xcd, n_groups = gpx * 8;
     {
         const uint4 *src = a.wp + (size_t)slice * kW16Img;
 #pragma unroll
@@ -135,6 +141,7 @@ __global__ __launch_bounds__(512, 1) void linear_ws16_kernel(Ws16Args a) {
     int e_cur = chunk_max(raw[0]), e_nxt = e_cur;  // per lane (= token): domain of its accumulators / scale of the fragments converted last
     split_x(raw[0], pow2i_w(e_cur), fb[0]);
     const uint4 *wb = Ws + hl * 128 + nl;
+    float4 *stg = reinterpret_cast<float4 *>(Ws + kW16Img) + wave * (32 * 8);      // per-wave output transpose, 4 KiB
     for (; tile < t_end; tile += 8) {
         const int next = tile + 8;
         const float4 *xn = row_ptr(next < t_end ? next : tile);
@@ -144,13 +151,13 @@ __global__ __launch_bounds__(512, 1) void linear_ws16_kernel(Ws16Args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
+        for (int c = 0; c < NCH; ++c) {
             // raw[(c + 1) & 3] holds chunk c+1 (of this tile, or chunk 0 of the next): converted under the MFMAs of chunk c;
             // raw[(c + 3) & 3] is free: chunk c+3 goes there
-            if (c + 3 < 8) fetch(xp, c + 3, raw[(c + 3) & 3]);
-            else fetch(xn, c + 3 - 8, raw[(c + 3) & 3]);
+            if (c + 3 < NCH) fetch(xp, c + 3, raw[(c + 3) & 3]);
+            else fetch(xn, c + 3 - NCH, raw[(c + 3) & 3]);
             const int e_chunk = chunk_max(raw[(c + 1) & 3]);
-            e_nxt = (c == 7) ? e_chunk : min(e_cur, e_chunk);       // a new tile starts its own running scale
+            e_nxt = (c == NCH - 1) ? e_chunk : min(e_cur, e_chunk);       // a new tile starts its own running scale
             const float sc = pow2i_w(e_nxt);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(512, 1) void linear_ws16_kernel(Ws16Args a) {
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) wf[j][p] = wb[((p * 16 + 2 * c + s) * 2) * 128 + 32 * j];
+                    for (int j = 0; j < 4; ++j) wf[j][p] = wb[((p * KS + 2 * c + s) * 2) * 128 + 32 * j];
                 const f16x8w xh = __builtin_bit_cast(f16x8w, fb[c & 1][s][0]), xl = __builtin_bit_cast(f16x8w, fb[c & 1][s][1]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -174,33 +181,41 @@ __global__ __launch_bounds__(512, 1) void linear_ws16_kernel(Ws16Args a) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
             }
-            if (c < 7 && __builtin_amdgcn_ballot_w64(e_nxt != e_cur) != 0) {   // a token's running scale dropped: new domain
+            if (c < NCH - 1 && __builtin_amdgcn_ballot_w64(e_nxt != e_cur) != 0) {   // a token's running scale dropped: new domain
                 const float rs = __builtin_amdgcn_ldexpf(1.0f, e_nxt - e_cur);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[j][r] *= rs;
             }
-            if (c < 7) e_cur = e_nxt;
+            if (c < NCH - 1) e_cur = e_nxt;
         }
-        // epilogue: lane = token nl, registers = features 32 j + 8 g + 4 hl + (0..3): 16-byte stores
-        const long long t = (long long)tile * 32 + nl;
+        // epilogue: lane = token nl, registers = features 32 j + 8 g + 4 hl + (0..3).  Through a per-wave LDS transpose
+        // ([token][8 float4], float4 slot XOR-swizzled by the token so that neither side conflicts) so that 8 lanes store the 128
+        // contiguous bytes of one token's 32 features: a direct store would scatter 32-byte pieces at the row stride.
         const int un = -(e_cur + a.w_exp);
-        if (t < a.T) {
-            float *op = out + t * a.ldo + 4 * hl;
+        const long long tbase = (long long)tile * 32;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float4 v = make_float4(__builtin_amdgcn_ldexpf(acc[j][4 * g], un), __builtin_amdgcn_ldexpf(acc[j][4 * g + 1], un),
-                                           __builtin_amdgcn_ldexpf(acc[j][4 * g + 2], un), __builtin_amdgcn_ldexpf(acc[j][4 * g + 3], un));
-                    if (bias) {
-                        const float4 b4 = *reinterpret_cast<const float4 *>(bias + 32 * j + 8 * g + 4 * hl);
-                        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-                    }
-                    if (a.act == 6) { v.x = gelu_w(v.x); v.y = gelu_w(v.y); v.z = gelu_w(v.z); v.w = gelu_w(v.w); }
-                    *reinterpret_cast<float4 *>(op + 32 * j + 8 * g) = v;
+            for (int g = 0; g < 4; ++g) {
+                float4 v = make_float4(__builtin_amdgcn_ldexpf(acc[j][4 * g], un), __builtin_amdgcn_ldexpf(acc[j][4 * g + 1], un),
+                                       __builtin_amdgcn_ldexpf(acc[j][4 * g + 2], un), __builtin_amdgcn_ldexpf(acc[j][4 * g + 3], un));
+                if (bias) {
+                    const float4 b4 = *reinterpret_cast<const float4 *>(bias + 32 * j + 8 * g + 4 * hl);
+                    v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
                 }
+                if (a.act == 6) { v.x = gelu_w(v.x); v.y = gelu_w(v.y); v.z = gelu_w(v.z); v.w = gelu_w(v.w); }
+                stg[nl * 8 + ((2 * g + hl) ^ (nl & 7))] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int tk = (lane >> 3) + 8 * q, c4 = lane & 7;
+                const float4 v = stg[tk * 8 + (c4 ^ (tk & 7))];
+                if (tbase + tk < a.T) *reinterpret_cast<float4 *>(out + (tbase + tk) * a.ldo + 32 * j + 4 * c4) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
         e_cur = e_nxt;
         xp = xn;
@@ -220,18 +235,23 @@ int ct_linear_ws16_f32(const float *x, const float *x2, int k1, const void *wp16
     ct::Ws16Args a;
     const bool nsl = (k == 256) && (n % 128 == 0);
     const bool ksl = !nsl && (n == 128) && (k % 256 == 0) && !x2;
-    if (!nsl && !ksl) return CT_E_BADARG;
-    a.S = nsl ? n / 128 : k / 256;
-    if (a.S < 1 || a.S > 32 || (32 % a.S)) return CT_E_BADARG;
+    const bool slab = !nsl && !ksl && (k == 128) && (n % 128 == 0) && !x2;     // out = [n/128][tokens][128]
+    if (!nsl && !ksl && !slab) return CT_E_BADARG;
+    a.S = ksl ? k / 256 : n / 128;
+    if (a.S < 1 || a.S > 32 || (a.S != 3 && (32 % a.S))) return CT_E_BADARG;
     if (nsl) {
         if (x2 ? (k1 != 128) : (k1 != 256)) return CT_E_BADARG;
         a.xa = x; a.lda = x2 ? 128 : 256;
         a.xb = x2 ? x2 : x + 128; a.ldb = x2 ? 128 : 256;
         a.x_slice = 0; a.ldo = n; a.out_slice = 128; a.kslices = 0;
-    } else {
+    } else if (ksl) {
         if (k1 != k || act != 0) return CT_E_BADARG;
         a.xa = x; a.xb = x + 128; a.lda = a.ldb = k;
         a.x_slice = 256; a.ldo = 128; a.out_slice = tokens * 128; a.kslices = 1;
+    } else {
+        if (k1 != k) return CT_E_BADARG;
+        a.xa = x; a.xb = x + 64; a.lda = a.ldb = 128;
+        a.x_slice = 0; a.ldo = 128; a.out_slice = tokens * 128; a.kslices = 0;
     }
     if (tokens == 0) return CT_OK;
     a.wp = reinterpret_cast<const uint4 *>(wp16); a.w_exp = w_exp; a.bias = bias; a.out = out; a.T = tokens;
@@ -239,11 +259,14 @@ int ct_linear_ws16_f32(const float *x, const float *x2, int k1, const void *wp16
     if (nt > 0x7fffffffLL) return CT_E_BADARG;
     a.n_tiles = (int)nt; a.act = act;
     static const bool attr = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(ct::linear_ws16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   ct::kW16Img * 16) == hipSuccess;
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(ct::linear_ws16_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   ct::w16_img(8) * 16 + 32768) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void *>(ct::linear_ws16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   ct::w16_img(4) * 16 + 32768) == hipSuccess;
     }();
     if (!attr) return CT_E_BADARG;
-    hipLaunchKernelGGL(ct::linear_ws16_kernel, dim3(256), dim3(512), ct::kW16Img * 16, (hipStream_t)stream, a);
+    if (slab) hipLaunchKernelGGL(ct::linear_ws16_kernel<4>, dim3(256), dim3(512), ct::w16_img(4) * 16 + 32768, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(ct::linear_ws16_kernel<8>, dim3(256), dim3(512), ct::w16_img(8) * 16 + 32768, (hipStream_t)stream, a);
     CT_CHECK_LAUNCH();
     return CT_OK;
 }

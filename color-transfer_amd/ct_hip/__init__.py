@@ -995,8 +995,10 @@ def pack_linear_weight_ws16(weight):
         img = pieces.reshape(2, n // 128, 128, 2, 16, 8).permute(1, 0, 4, 3, 2, 5)       # slice, piece, s, h, f, j
     elif n == 128 and k % 256 == 0:
         img = pieces.reshape(2, 128, k // 256, 2, 16, 8).permute(2, 0, 4, 3, 1, 5)
+    elif k == 128 and n % 128 == 0:                                        # 128-channel slices: channel = 64 h + 8 s + j, s < 8
+        img = pieces.reshape(2, n // 128, 128, 2, 8, 8).permute(1, 0, 4, 3, 2, 5)
     else:
-        raise CtHipError("pack_linear_weight_ws16: K == 256 with N % 128 == 0, or N == 128 with K % 256 == 0")
+        raise CtHipError("pack_linear_weight_ws16: K in (128, 256) with N % 128 == 0, or N == 128 with K % 256 == 0")
     return img.contiguous(), w_exp
 
 
@@ -1010,6 +1012,31 @@ def _packed_linear_ws16(weight):
 
 
 _lin_ws16 = os.environ.get("CT_HIP_LINEAR_WS16", "1") != "0"
+
+
+def linear_tokens_multi(x, weights, biases=None, mode=None):
+    """[linear_tokens(x, w, b) for w, b in zip(weights, biases)] for up to four 128 -> 128 layers reading the SAME tokens (the q / k /
+    v projections of a transformer layer, transformer.py:26-31): one launch of ct_linear_ws16_f32 whose feature slices share the
+    tokens through L2 and write one result slab each.  Falls back to separate calls where that kernel does not apply."""
+    biases = list(biases) if biases is not None else [None] * len(weights)
+    k = x.shape[-1]
+    t = x.numel() // k
+    ok = ((mode or _conv_mode) == "split" and _lin_ws16 and k == 128 and 1 <= len(weights) <= 4 and t >= 4096 and
+          all(tuple(w.shape) == (128, 128) for w in weights) and (all(b is None for b in biases) or all(b is not None for b in biases)))
+    if not ok:
+        return [linear_tokens(x, w, b, mode=mode) for w, b in zip(weights, biases)]
+    _f32c(x, *weights, *biases)
+    ver = tuple((w._version, w.data_ptr()) for w in weights) + (str(x.device),)
+    hit = getattr(weights[0], "_ct_lin_ws16_multi", None)
+    if hit is None or hit[0] != ver:
+        hit = (ver, pack_linear_weight_ws16(torch.cat([w.detach() for w in weights], dim=0)))
+        weights[0]._ct_lin_ws16_multi = hit
+    img, w_exp = hit[1]
+    bias = torch.cat([b.detach().float() for b in biases]) if biases[0] is not None else None
+    out = torch.empty((len(weights),) + tuple(x.shape[:-1]) + (128,), dtype=torch.float32, device=x.device)
+    check(lib().ct_linear_ws16_f32(_ptr(x), _c_p(0), 128, _ptr(img), int(w_exp), _opt(bias), _ptr(out), t, 128, 128 * len(weights), 0,
+                                   _stream()))
+    return [out[i] for i in range(len(weights))]
 
 
 def set_linear_ws16(on):

@@ -266,7 +266,12 @@ class GMFlow(nn.Module):
     def _tlayer(self, m, source, target, h, w, shift, splits, kv_swap=False):   # transformer.py:45-147
         """kv_swap: the layer's target is `target` with the two halves of the batch exchanged (the reference's concat1): the
         projections are per token, so they run on `target` as it is and the attention reads the keys / values of the other half"""
-        q, k, v = _lin(m.q_proj, source), _lin(m.k_proj, target), _lin(m.v_proj, target)
+        # the projections reading the same tokens share one launch (feature slices of the resident-weight linear)
+        if source is target:
+            q, k, v = ct_hip.linear_tokens_multi(source, [m.q_proj.weight, m.k_proj.weight, m.v_proj.weight])
+        else:
+            q = _lin(m.q_proj, source)
+            k, v = ct_hip.linear_tokens_multi(target, [m.k_proj.weight, m.v_proj.weight])
         msg = _lin(m.merge, self._window_attention(q, k, v, splits, shift, h, w, kv_swap))
         g1, b1 = m.norm1.weight.detach(), m.norm1.bias.detach()
         if m.no_ffn:

@@ -322,9 +322,12 @@ int ct_linear_tokens_split_f32(const float *x, const float *x2, int k1, const vo
  *   k == 256, n % 128 == 0, n / 128 in {1,2,4,8}: out[tokens][n] = act(x' w^T + bias); x' = [x[t][0:128] | x2[t][0:128]] (k1 = 128)
  *        or x[t][0:256] (x2 = NULL, k1 = 256);
  *   n == 128, k % 256 == 0, k / 256 in {1,2,4,8}, x2 = NULL, act = 0: out = PARTIAL slabs [k/256][tokens][128] whose sum is the
- *        result (bias in slab 0) -- ct_layernorm128_f32(partials = k/256) adds them in slab order on its way in.
+ *        result (bias in slab 0) -- ct_layernorm128_f32(partials = k/256) adds them in slab order on its way in;
+ *   k == 128, n % 128 == 0, n / 128 in {1,2,3,4}, x2 = NULL: several 128 -> 128 layers reading the same tokens in one launch (the
+ *        q / k / v projections, transformer.py:26-31; w = their weights stacked): out = slabs [n/128][tokens][128], one per layer.
  * wp16: ct_hip.pack_linear_weight_ws16: fp16 bit patterns [slice][piece hi/lo][k step 0..15][lane half][feature 0..127][8 channels]
- * of w * 2^w_exp, channel of (step s, half h, j) = 128 h + 8 s + j within the slice.  act: 0 none, 6 exact GELU.            */
+ * of w * 2^w_exp, channel of (step s, half h, j) = 128 h + 8 s + j within the slice (k == 128: 8 steps, 64 h + 8 s + j).
+ * act: 0 none, 6 exact GELU.                                                                                                */
 int ct_linear_ws16_f32(const float *x, const float *x2, int k1, const void *wp16, int w_exp, const float *bias, float *out,
                        long long tokens, int k, int n, int act, void *stream);
 /* LayerNorm(128, eps 1e-5, affine) on tokens, out = residual + LN(x) when residual != NULL (transformer.py:139-147);

@@ -388,3 +388,20 @@ def test_linear_ws16_wide_dynamic_range(hip):
     assert lib.ct_linear_ws16_f32(p, None, 256, p, 0, None, p, 64, 256, 96, 0, None) == -1      # n % 128
     assert lib.ct_linear_ws16_f32(p, None, 1024, p, 0, None, p, 64, 1024, 128, 6, None) == -1   # no activation on partial slabs
     assert lib.ct_linear_ws16_f32(p, None, 256, p, 0, None, p, 0, 256, 128, 0, None) == 0       # no tokens
+
+
+@pytest.mark.parametrize("count,t,bias", [(3, 4096, False), (2, 5001, True), (1, 4100, False), (4, 8192, True)])
+def test_linear_tokens_multi(hip, count, t, bias):
+    """several 128 -> 128 projections of the same tokens in one launch (slab outputs of ct_linear_ws16_f32) == the separate layers"""
+    x = rnd(2, t // 2 if t % 2 == 0 else t, 128) if t % 2 == 0 else rnd(t, 128)
+    ws = [(rnd(128, 128) / 128 ** 0.5 * (10.0 ** i)).cuda() for i in range(count)]
+    bs = [rnd(128).cuda() for _ in range(count)] if bias else None
+    outs = hip.linear_tokens_multi(x.cuda(), ws, bs)
+    assert hasattr(ws[0], "_ct_lin_ws16_multi") and len(outs) == count
+    for i, o in enumerate(outs):
+        ref = F.linear(x.double(), ws[i].double().cpu(), bs[i].double().cpu() if bias else None)
+        assert o.shape == x.shape and o.is_contiguous()
+        bound = F.linear(x.double().abs(), ws[i].double().cpu().abs()) + (bs[i].double().cpu().abs() if bias else 0) + 1e-300
+        assert ((o.double().cpu() - ref).abs() / bound).max().item() < 1e-6
+    small = hip.linear_tokens_multi(x.cuda()[..., :64, :].contiguous(), ws, bs)       # few tokens: the separate kernels
+    assert len(small) == count and small[0].shape[-1] == 128

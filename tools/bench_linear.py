@@ -40,3 +40,21 @@ for T, k, n, act in SHAPES:
             ms = t_ms(call, 24)
             line += "  %s %.3f ms %6.1f TFLOP/s err %.2g" % (mode, ms, 2.0 * T * k * n / ms / 1e9, err)
         print(line)
+
+# the q / k / v projections: three separate launches vs one three-slice launch
+for T in (14336, 114688):
+    xs = [torch.randn(T, 128, device="cuda") for _ in range(ROT)]
+    ws = [torch.randn(128, 128, device="cuda") / 128 ** 0.5 for _ in range(3)]
+    it = [0]
+    def sep():
+        it[0] += 1
+        return [ct_hip.linear_tokens(xs[it[0] % ROT], w, None, mode="split") for w in ws]
+    def multi():
+        it[0] += 1
+        return ct_hip.linear_tokens_multi(xs[it[0] % ROT], ws)
+    def one():
+        it[0] += 1
+        return ct_hip.linear_tokens_multi(xs[it[0] % ROT], ws[:1])
+    ct_hip.set_linear_ws16(True)
+    print("T=%6d q/k/v 128->128: separate %.3f ms  one launch %.3f ms;  single layer: wres %.3f ms  ws16 %.3f ms" % (
+        T, t_ms(sep, 24), t_ms(multi, 24), t_ms(lambda: (it.__setitem__(0, it[0] + 1), ct_hip.linear_tokens(xs[it[0] % ROT], ws[0], None, mode="split"))[1], 24), t_ms(one, 24)))
