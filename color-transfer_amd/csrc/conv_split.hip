@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
     extern __shared__ uint4 smem16[];
     constexpr int WSLOT = NP * MT * 64;                 // 16-byte entries of one tap's weight fragments
     uint4 *tin = smem16;                                // [NP][ROWS][2][TWP]
-    constexpr int WRING = 4;                            // taps of weights resident in LDS
+    constexpr int WRING = F16 ? 8 : 4;                  // taps of weights resident in LDS (4 KiB each as two pieces, 6 KiB as three)
+    constexpr int WAHEAD = WRING - 1;                   // a tap's fragments are requested WAHEAD taps before their use
     uint4 *wl = smem16 + NP * PSZ;                      // [WRING][piece][m][lane]
     float *stg = reinterpret_cast<float *>(smem16 + NP * PSZ + WRING * WSLOT) + (threadIdx.x >> 6) * (32 * 32);
     float *mxw = reinterpret_cast<float *>(smem16 + NP * PSZ + WRING * WSLOT) + 4 * (32 * 32);   // F16: the waves' tile maxima
@@ -220,10 +221,25 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
     };
     // before the barrier that ends tap g: the fragments of tap g+1 have landed (loads of later taps may be in flight)
     auto w_landed = [&](int g) {
-        const int ahead = n_gtaps - g - 2;                 // taps issued after tap g+1
-        if (ahead >= 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * NP * MT));     // vmcnt(12) (8 with two pieces)
-        else if (ahead == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (NP * MT));    // vmcnt(6) (4)
-        else __builtin_amdgcn_s_waitcnt(0x0F70);                                 // vmcnt(0)
+        const int ahead = min(n_gtaps - g - 2, WAHEAD - 1);   // taps issued after tap g+1 (their loads may still be in flight)
+        // vmcnt(ahead * NP * MT): the counter has six bits, [3:0] and [15:14] of the immediate
+#define CT_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
+        if constexpr (WAHEAD == 3) {
+            if (ahead >= 2) CT_VMCNT(2 * NP * MT);
+            else if (ahead == 1) CT_VMCNT(NP * MT);
+            else CT_VMCNT(0);
+        } else {
+            switch (ahead) {
+                case 6: CT_VMCNT(6 * NP * MT); break;
+                case 5: CT_VMCNT(5 * NP * MT); break;
+                case 4: CT_VMCNT(4 * NP * MT); break;
+                case 3: CT_VMCNT(3 * NP * MT); break;
+                case 2: CT_VMCNT(2 * NP * MT); break;
+                case 1: CT_VMCNT(NP * MT); break;
+                default: CT_VMCNT(0); break;
+            }
+        }
+#undef CT_VMCNT
     };
 
 #ifdef CT_CONV_PROFILE
@@ -305,8 +321,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
     };
 
     w_issue(0);
-    if (n_gtaps > 1) w_issue(1);
-    if (n_gtaps > 2) w_issue(2);
+    for (int g0 = 1; g0 < WAHEAD && g0 < n_gtaps; ++g0) w_issue(g0);
     if (wloader) w_landed(-1);
     fetch_tile(0);
     if constexpr (F16) {
@@ -411,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
         for (int tap = 0; tap < TAPS; ++tap) {
             const bool last_tap = (tap + 1 == TAPS);
             const int g = stage * TAPS + tap;
-            if (g + 3 < n_gtaps) w_issue(g + 3);   // slot (g+3)%4 was last read in tap g-1: free since that barrier
+            if (g + WAHEAD < n_gtaps) w_issue(g + WAHEAD);   // its slot was last read in tap g-1: free since that barrier
             if (tap == 0 && next_stage) fetch_tile(stage + 1);   // next halo tile: in flight under this stage's MFMAs
             if (!last_tap) read_b(tap + 1, bn);
             mfma6(wl + (g % WRING) * WSLOT + lane, bc);
@@ -590,7 +605,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
 template <int KH, int KW, bool GEN, bool F16 = false>
 static int launch_split(const ConvArgs &a, int N, hipStream_t s) {
     constexpr int ROWS = kSpTH + KH - 1, TWP = (KW > 1) ? kSpTW + 8 : kSpTW, NP = F16 ? 2 : 3;
-    const size_t lds = (size_t)NP * ROWS * 2 * TWP * 16 + (size_t)4 * NP * 2 * 64 * 16 + (size_t)4 * 32 * 32 * sizeof(float) + 16;
+    const size_t lds = (size_t)NP * ROWS * 2 * TWP * 16 + (size_t)(F16 ? 8 : 4) * NP * 2 * 64 * 16 + (size_t)4 * 32 * 32 * sizeof(float) + 16;
     const int tiles_x = (a.W + kSpTW - 1) / kSpTW, tiles_y = (a.H + kSpTH - 1) / kSpTH;
     const long long n_tiles = (long long)tiles_x * tiles_y * N * a.groups;
     if (n_tiles > 0x7fffffffLL) return CT_E_BADARG;

@@ -1396,8 +1396,8 @@ __global__ __launch_bounds__(256) void local_corr_softmax_kernel(const float *__
 // All (2R+1)^2 window taps of a pixel sample feature1 at integer offsets from ONE point (x + flow), so they share the
 // bilinear weights: corr(dx,dy) = w00 D(dx,dy) + w01 D(dx+1,dy) + w10 D(dx,dy+1) + w11 D(dx+1,dy+1) with the (2R+2)^2
 // integer-offset dots D(i,j) = <f0[pix], f1[y0-R+j][x0-R+i]> (zero outside the image = grid_sample's zero padding).
-// That is 100 dots per pixel instead of 4 x 81.  One wave per pixel at a time: lane <-> window position, walking its
-// 512-byte channel vector with 16-byte loads against the pixel's f0 vector broadcast from LDS.  A workgroup covers 32
+// That is 100 dots per pixel instead of 4 x 81.  One wave per pixel at a time: eight lanes per window position, each with 16
+// channels of the position's 512-byte vector (whole cache lines per load instruction) against its part of the pixel's f0 vector.  A workgroup covers 32
 // consecutive pixels (4 waves x 8) and writes each of the 81 correlation planes as one 128-byte segment.
 constexpr int kLcfPix = 32;    // pixels per workgroup
 
@@ -1430,20 +1430,32 @@ __global__ __launch_bounds__(256) void local_corr_flow_kernel(const float *__res
         const int x0 = (x0f > -1e6f && x0f < 1e6f) ? (int)x0f : -1000000, y0 = (y0f > -1e6f && y0f < 1e6f) ? (int)y0f : -1000000;
         *reinterpret_cast<float2 *>(&a_s[wave][2 * lane]) = *reinterpret_cast<const float2 *>(f0 + ((size_t)b * hw + pix) * C + 2 * lane);
         __builtin_amdgcn_wave_barrier();
-        for (int p = lane; p < NP; p += 64) {
-            const int jj = p / DP, ii = p - jj * DP;
-            const int xx = x0 - R + ii, yy = y0 - R + jj;
-            float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
-            if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
-                const float *bp = f1 + ((size_t)b * hw + (size_t)yy * W + xx) * C;
-#pragma unroll 8
-                for (int c = 0; c < C; c += 4) {
-                    const float4 u = *reinterpret_cast<const float4 *>(&a_s[wave][c]);
-                    const float4 w4 = *reinterpret_cast<const float4 *>(bp + c);
-                    d0 = fmaf(u.x, w4.x, d0); d1 = fmaf(u.y, w4.y, d1); d2 = fmaf(u.z, w4.z, d2); d3 = fmaf(u.w, w4.w, d3);
+        // eight lanes per window position, 16 channels each: a load instruction reads eight whole 128-byte lines (one lane per
+        // position would touch 64 lines per instruction, a quarter of each)
+        {
+            const int ps = lane >> 3, oc = lane & 7;
+            float4 u[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) u[i] = *reinterpret_cast<const float4 *>(&a_s[wave][16 * oc + 4 * i]);
+            for (int p0 = 0; p0 < NP; p0 += 8) {
+                const int p = p0 + ps;
+                const int jj = p / DP, ii = p - jj * DP;
+                const int xx = x0 - R + ii, yy = y0 - R + jj;
+                float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+                if (p < NP && xx >= 0 && xx < W && yy >= 0 && yy < H) {
+                    const float *bp = f1 + ((size_t)b * hw + (size_t)yy * W + xx) * C + 16 * oc;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float4 w4 = *reinterpret_cast<const float4 *>(bp + 4 * i);
+                        d0 = fmaf(u[i].x, w4.x, d0); d1 = fmaf(u[i].y, w4.y, d1); d2 = fmaf(u[i].z, w4.z, d2); d3 = fmaf(u[i].w, w4.w, d3);
+                    }
                 }
+                float d = (d0 + d1) + (d2 + d3);
+                d += __shfl_xor(d, 1, 64);
+                d += __shfl_xor(d, 2, 64);
+                d += __shfl_xor(d, 4, 64);
+                if (oc == 0 && p < NP) d_s[wave][p] = d;
             }
-            d_s[wave][p] = (d0 + d1) + (d2 + d3);
         }
         __builtin_amdgcn_wave_barrier();
         for (int t = lane; t < NT; t += 64) {
