@@ -205,7 +205,11 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
     auto w_issue = [&](int /*g*/) {
         const uint4 *src = wp16 + ((((size_t)wi_grp * n_chunks + wi_chunk) * TAPS + wi_tap) * NP * MT) * 64 + lane;
         const unsigned int dst = wl_addr + (unsigned int)(wi_slot * WSLOT * 16);   // + 16 * lane is implied by the instruction
+#ifdef CT_SPLIT_ABL_NOW
+        if (wloader && wi_k == 0 && wi_chunk == 0) {       // diagnostic: only the first stage's weights are ever loaded
+#else
         if (wloader) {                                     // the cursor below advances in every wave: it stays scalar
+#endif
 #pragma unroll
             for (int f = 0; f < NP * MT; ++f) glds16(src + f * 64, __builtin_amdgcn_readfirstlane(dst + f * 1024));
         }
@@ -695,14 +699,15 @@ int ct_conv2d_split_rows_f32(const float *in, const void *wp_split, const float 
 
 #ifdef CT_CONV_PROFILE
 int ct_conv2d_split_prof_f32(const float *in, const void *wp_split, const float *bias, const float *residual, float *out, int n,
-                             int cin, int cout, int h, int w, unsigned long long *prof, void *stream) {
+                             int cin, int cout, int h, int w, unsigned long long *prof, int f16, int w_exp, int kh, int kw, void *stream) {
     ct::ConvArgs a;
     a.in = in; a.in2 = nullptr; a.cin1 = cin; a.in2_bstride = 0;
     a.wp = reinterpret_cast<const float *>(wp_split); a.bias = bias; a.residual = residual; a.out = out;
     a.cin = cin; a.cout = cout; a.H = h; a.W = w;
     a.in_bstride = (long long)cin * h * w; a.out_bstride = (long long)cout * h * w; a.res_bstride = a.out_bstride;
     a.act = 0; a.clamp = 0; a.groups = (cout + 63) / 64; a.prof = prof;
-    return ct::conv_split(a, n, 3, 3, false, (hipStream_t)stream);
+    a.f16 = f16; a.w_exp = w_exp;
+    return ct::conv_split(a, n, kh, kw, f16 != 0, (hipStream_t)stream);
 }
 #endif
 

@@ -153,6 +153,49 @@ def test_conv_weight_packing_layout():
     assert torch.equal(bp[:5], b) and bp[5:].abs().sum() == 0
 
 
+def test_fp16_piece_packings_layout_and_value():
+    """the host packings of the two-piece fp16 kernels: hi + lo == weight * 2^w_exp to 2^-22 relative, the largest weight in
+    [2^11, 2^12), and every (slice, piece, step, half, feature, channel) index where include/ct_hip.h says it is"""
+    import ct_hip
+    g = torch.Generator().manual_seed(3)
+
+    def pieces_value(img):                              # int16 bit patterns [..., piece axis first of the two given] -> float64
+        return img.view(torch.float16).double()
+    # linear, feature slices of 256 channels (FFN1), channel slices (FFN2), 128-channel slices (q / k / v stacked)
+    for n, k in ((256, 256), (128, 512), (384, 128)):
+        w = torch.randn(n, k, generator=g) * 0.03
+        img, w_exp = ct_hip.pack_linear_weight_ws16(w)
+        amax = (w.abs().max() * 2.0 ** w_exp).item()
+        assert 2048 <= amax < 4096
+        v = pieces_value(img)
+        steps = 16 if k != 128 else 8
+        half = 8 * steps
+        if k == 256 or k == 128:
+            assert img.shape == (n // 128, 2, steps, 2, 128, 8)
+            for (sl, s, h, f, j) in [(0, 0, 0, 0, 0), (n // 128 - 1, steps - 1, 1, 127, 7), (0, 3, 1, 17, 5)]:
+                want = w[128 * sl + f, half * h + 8 * s + j].double() * 2.0 ** w_exp
+                got = v[sl, 0, s, h, f, j] + v[sl, 1, s, h, f, j]
+                assert abs(got - want) <= 2.0 ** -21 * abs(want) + 2.0 ** -24
+        else:
+            assert img.shape == (k // 256, 2, 16, 2, 128, 8)
+            for (sl, s, h, f, j) in [(0, 0, 0, 0, 0), (1, 15, 1, 127, 7), (1, 2, 0, 9, 3)]:
+                want = w[f, 256 * sl + 128 * h + 8 * s + j].double() * 2.0 ** w_exp
+                got = v[sl, 0, s, h, f, j] + v[sl, 1, s, h, f, j]
+                assert abs(got - want) <= 2.0 ** -21 * abs(want) + 2.0 ** -24
+    # convolution, any tap count: [group][chunk16][tap][piece][m][k-half][cout % 32][8 channels]
+    for (cout, cin, kh, kw) in ((70, 40, 1, 5), (64, 64, 3, 3), (5, 3, 1, 1)):
+        w = torch.randn(cout, cin, kh, kw, generator=g) * 1e-3
+        img, w_exp = ct_hip.pack_conv_weight_split16(w)
+        assert img.shape == ((cout + 63) // 64, (cin + 15) // 16, kh * kw, 2, 2, 2, 32, 8)
+        v = pieces_value(img)
+        for (co, ci, ky, kx) in [(0, 0, 0, 0), (cout - 1, cin - 1, kh - 1, kw - 1), (cout // 2, cin // 3, 0, kw // 2)]:
+            want = w[co, ci, ky, kx].double() * 2.0 ** w_exp
+            idx = (co // 64, ci // 16, ky * kw + kx, slice(None), (co % 64) // 32, (ci % 16) // 8, co % 32, ci % 8)
+            got = v[idx].sum()
+            assert abs(got - want) <= 2.0 ** -21 * abs(want) + 2.0 ** -24
+        assert v[(cout + 63) // 64 - 1, :, :, :, 1, :, (cout % 32 or 32):].abs().sum() == 0 or cout % 64 == 0 or cout % 64 > 32
+
+
 def test_sharding_arithmetic():
     from utils import sharding as sh
     assert sh.frames_of_rank(10, 1, 4) == [1, 5, 9]
