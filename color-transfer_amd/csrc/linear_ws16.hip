@@ -76,6 +76,8 @@ struct Ws16Args {
     int S;                         // slices (1, 2, 3, 4, 8, 16, 32: floor(32 / S) token groups per XCD)
     int kslices;                   // 1 = K slices (partials), 0 = N slices
     int act;                       // 0 none, 6 GELU
+    const float *ln_g, *ln_b;      // non-NULL (one slice of 128 features only): out = [ln_res +] LayerNorm_128(result) (eps 1e-5)
+    const float *ln_res;           // nullable: the residual rows [T][128]
 };
 
 template <int NCH>
@@ -195,25 +197,62 @@ __global__ __launch_bounds__(512, 1) void linear_ws16_kernel(Ws16Args a) {
         // contiguous bytes of one token's 32 features: a direct store would scatter 32-byte pieces at the row stride.
         const int un = -(e_cur + a.w_exp);
         const long long tbase = (long long)tile * 32;
+        float ln_mean = 0.f, ln_rstd = 1.f;
+        if (NCH == 4 && a.ln_g) {
+            // LayerNorm over the token's 128 features (transformer.py:139-147): they are this lane's 64 registers and its
+            // partner's (32 lanes apart); two passes over registers like layernorm_tokens_kernel
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc[j][r] = __builtin_amdgcn_ldexpf(acc[j][r], un);
+                    if (bias) acc[j][r] += bias[32 * j + 8 * (r >> 2) + 4 * hl + (r & 3)];
+                    sum += acc[j][r];
+                }
+            sum += __shfl_xor(sum, 32, 64);
+            ln_mean = sum * (1.0f / 128.0f);
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float d = acc[j][r] - ln_mean; ss = fmaf(d, d, ss); }
+            ss += __shfl_xor(ss, 32, 64);
+            ln_rstd = 1.0f / sqrtf(ss * (1.0f / 128.0f) + 1e-5f);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float4 v = make_float4(__builtin_amdgcn_ldexpf(acc[j][4 * g], un), __builtin_amdgcn_ldexpf(acc[j][4 * g + 1], un),
-                                       __builtin_amdgcn_ldexpf(acc[j][4 * g + 2], un), __builtin_amdgcn_ldexpf(acc[j][4 * g + 3], un));
-                if (bias) {
-                    const float4 b4 = *reinterpret_cast<const float4 *>(bias + 32 * j + 8 * g + 4 * hl);
-                    v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+                float4 v;
+                if (NCH == 4 && a.ln_g) {
+                    const float4 g4 = *reinterpret_cast<const float4 *>(a.ln_g + 32 * j + 8 * g + 4 * hl);
+                    const float4 b4 = *reinterpret_cast<const float4 *>(a.ln_b + 32 * j + 8 * g + 4 * hl);
+                    v = make_float4((acc[j][4 * g] - ln_mean) * ln_rstd * g4.x + b4.x, (acc[j][4 * g + 1] - ln_mean) * ln_rstd * g4.y + b4.y,
+                                    (acc[j][4 * g + 2] - ln_mean) * ln_rstd * g4.z + b4.z, (acc[j][4 * g + 3] - ln_mean) * ln_rstd * g4.w + b4.w);
+                } else {
+                    v = make_float4(__builtin_amdgcn_ldexpf(acc[j][4 * g], un), __builtin_amdgcn_ldexpf(acc[j][4 * g + 1], un),
+                                    __builtin_amdgcn_ldexpf(acc[j][4 * g + 2], un), __builtin_amdgcn_ldexpf(acc[j][4 * g + 3], un));
+                    if (bias) {
+                        const float4 b4 = *reinterpret_cast<const float4 *>(bias + 32 * j + 8 * g + 4 * hl);
+                        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+                    }
+                    if (a.act == 6) { v.x = gelu_w(v.x); v.y = gelu_w(v.y); v.z = gelu_w(v.z); v.w = gelu_w(v.w); }
                 }
-                if (a.act == 6) { v.x = gelu_w(v.x); v.y = gelu_w(v.y); v.z = gelu_w(v.z); v.w = gelu_w(v.w); }
                 stg[nl * 8 + ((2 * g + hl) ^ (nl & 7))] = v;
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int tk = (lane >> 3) + 8 * q, c4 = lane & 7;
-                const float4 v = stg[tk * 8 + (c4 ^ (tk & 7))];
-                if (tbase + tk < a.T) *reinterpret_cast<float4 *>(out + (tbase + tk) * a.ldo + 32 * j + 4 * c4) = v;
+                float4 v = stg[tk * 8 + (c4 ^ (tk & 7))];
+                if (tbase + tk < a.T) {
+                    if (NCH == 4 && a.ln_res) {
+                        const float4 r4 = *reinterpret_cast<const float4 *>(a.ln_res + (tbase + tk) * 128 + 32 * j + 4 * c4);
+                        v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+                    }
+                    *reinterpret_cast<float4 *>(out + (tbase + tk) * a.ldo + 32 * j + 4 * c4) = v;
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -228,8 +267,12 @@ extern "C" {
 
 // see include/ct_hip.h
 int ct_linear_ws16_f32(const float *x, const float *x2, int k1, const void *wp16, int w_exp, const float *bias, float *out,
-                       long long tokens, int k, int n, int act, void *stream) {
+                       long long tokens, int k, int n, int act, const float *ln_gamma, const float *ln_beta, const float *ln_residual,
+                       void *stream) {
     if (!x || !wp16 || !out || tokens < 0 || (act != 0 && act != 6)) return CT_E_BADARG;
+    if ((ln_gamma != nullptr) != (ln_beta != nullptr) || (ln_residual && !ln_gamma)) return CT_E_BADARG;
+    if (ln_gamma && (k != 128 || n != 128 || x2 || act != 0)) return CT_E_BADARG;    // the fused LayerNorm needs a token's 128 features in one slice
+    if ((reinterpret_cast<uintptr_t>(ln_gamma) | reinterpret_cast<uintptr_t>(ln_beta) | reinterpret_cast<uintptr_t>(ln_residual)) & 15) return CT_E_ALIGN;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(x2) | reinterpret_cast<uintptr_t>(wp16) | reinterpret_cast<uintptr_t>(out) |
          reinterpret_cast<uintptr_t>(bias)) & 15) return CT_E_ALIGN;
     ct::Ws16Args a;
@@ -258,6 +301,7 @@ int ct_linear_ws16_f32(const float *x, const float *x2, int k1, const void *wp16
     const long long nt = (tokens + 31) / 32;
     if (nt > 0x7fffffffLL) return CT_E_BADARG;
     a.n_tiles = (int)nt; a.act = act;
+    a.ln_g = ln_gamma; a.ln_b = ln_beta; a.ln_res = ln_residual;
     static const bool attr = [] {
         return hipFuncSetAttribute(reinterpret_cast<const void *>(ct::linear_ws16_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    ct::w16_img(8) * 16 + 32768) == hipSuccess &&

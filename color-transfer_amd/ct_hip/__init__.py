@@ -772,7 +772,7 @@ SIGNATURES.update({
     "ct_linear_tokens_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p, ctypes.c_longlong, _c_int, _c_int, _c_int, _c_p]),
     "ct_linear_tokens_split_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p, ctypes.c_longlong, _c_int, _c_int, _c_int, _c_p]),
     "ct_layernorm128_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_p]),
-    "ct_linear_ws16_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p]),
+    "ct_linear_ws16_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p]),
     "ct_attention_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int, _c_int, _c_int]),
     "ct_attention_tokens_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_int, _c_p,
                                          ctypes.c_size_t, ctypes.c_longlong, _c_p]),
@@ -1035,8 +1035,22 @@ def linear_tokens_multi(x, weights, biases=None, mode=None):
     bias = torch.cat([b.detach().float() for b in biases]) if biases[0] is not None else None
     out = torch.empty((len(weights),) + tuple(x.shape[:-1]) + (128,), dtype=torch.float32, device=x.device)
     check(lib().ct_linear_ws16_f32(_ptr(x), _c_p(0), 128, _ptr(img), int(w_exp), _opt(bias), _ptr(out), t, 128, 128 * len(weights), 0,
-                                   _stream()))
+                                   _c_p(0), _c_p(0), _c_p(0), _stream()))
     return [out[i] for i in range(len(weights))]
+
+
+def linear_layernorm128(x, weight, bias, gamma, beta, residual=None, mode=None):
+    """[residual +] LayerNorm_128(linear(x, weight, bias)) for a 128 -> 128 layer (the merge projection with norm1 and the skip,
+    transformer.py:120-127,139-147): one launch of ct_linear_ws16_f32 where that kernel applies, else the two kernels"""
+    t = x.numel() // x.shape[-1]
+    if ((mode or _conv_mode) == "split" and _lin_ws16 and tuple(weight.shape) == (128, 128) and x.shape[-1] == 128 and t >= 4096):
+        _f32c(x, weight, bias, gamma, beta, residual)
+        img, w_exp = _packed_linear_ws16(weight)
+        out = torch.empty_like(x)
+        check(lib().ct_linear_ws16_f32(_ptr(x), _c_p(0), 128, _ptr(img), int(w_exp), _opt(bias), _ptr(out), t, 128, 128, 0,
+                                       _ptr(gamma), _ptr(beta), _opt(residual), _stream()))
+        return out
+    return layernorm128(linear_tokens(x, weight, bias, mode=mode), gamma, beta, residual=residual)
 
 
 def set_linear_ws16(on):
@@ -1066,7 +1080,7 @@ def linear_tokens(x, weight, bias=None, act=ACT_NONE, x2=None, mode=None, partia
             shape = ((k // 256,) if ksl else ()) + tuple(x.shape[:-1]) + (n,)
             out = torch.empty(shape, dtype=torch.float32, device=x.device)
             check(lib().ct_linear_ws16_f32(_ptr(x), _opt(x2), k1, _ptr(img), int(w_exp), _opt(bias), _ptr(out), t, k, n, int(act),
-                                           _stream()))
+                                           _c_p(0), _c_p(0), _c_p(0), _stream()))
             return out
     out = torch.empty(x.shape[:-1] + (n,), dtype=torch.float32, device=x.device)
     if (mode or _conv_mode) == "split" and k % 32 == 0:

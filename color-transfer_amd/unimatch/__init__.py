@@ -272,11 +272,12 @@ class GMFlow(nn.Module):
         else:
             q = _lin(m.q_proj, source)
             k, v = ct_hip.linear_tokens_multi(target, [m.k_proj.weight, m.v_proj.weight])
-        msg = _lin(m.merge, self._window_attention(q, k, v, splits, shift, h, w, kv_swap))
+        att = self._window_attention(q, k, v, splits, shift, h, w, kv_swap)
         g1, b1 = m.norm1.weight.detach(), m.norm1.bias.detach()
+        # merge projection + norm1 (+ the skip when the layer has no FFN) in one launch
+        msg = ct_hip.linear_layernorm128(att, m.merge.weight, m.merge.bias, g1, b1, residual=source if m.no_ffn else None)
         if m.no_ffn:
-            return ct_hip.layernorm128(msg, g1, b1, residual=source)
-        msg = ct_hip.layernorm128(msg, g1, b1)
+            return msg
         hid = _lin(m.mlp[0], source, act=ACT_GELU, x2=msg)                     # mlp(cat([source, message])), no copy
         x = ct_hip.linear_tokens(hid, m.mlp[2].weight, m.mlp[2].bias, partials=True)
         slabs = x.shape[0] if x.dim() == hid.dim() + 1 else 1                  # K-sliced: partial slabs, summed by the LayerNorm

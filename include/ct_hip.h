@@ -327,9 +327,11 @@ int ct_linear_tokens_split_f32(const float *x, const float *x2, int k1, const vo
  *        q / k / v projections, transformer.py:26-31; w = their weights stacked): out = slabs [n/128][tokens][128], one per layer.
  * wp16: ct_hip.pack_linear_weight_ws16: fp16 bit patterns [slice][piece hi/lo][k step 0..15][lane half][feature 0..127][8 channels]
  * of w * 2^w_exp, channel of (step s, half h, j) = 128 h + 8 s + j within the slice (k == 128: 8 steps, 64 h + 8 s + j).
- * act: 0 none, 6 exact GELU.                                                                                                */
+ * act: 0 none, 6 exact GELU.  ln_gamma / ln_beta != NULL (k = n = 128 only): out = [ln_residual +] LayerNorm_128(x w^T + bias) -- the
+ * merge projection with norm1 and the skip of transformer.py:120-127,139-147 in one launch.                                   */
 int ct_linear_ws16_f32(const float *x, const float *x2, int k1, const void *wp16, int w_exp, const float *bias, float *out,
-                       long long tokens, int k, int n, int act, void *stream);
+                       long long tokens, int k, int n, int act, const float *ln_gamma, const float *ln_beta,
+                       const float *ln_residual, void *stream);
 /* LayerNorm(128, eps 1e-5, affine) on tokens, out = residual + LN(x) when residual != NULL (transformer.py:139-147);
  * partials > 1: x is [partials][tokens][128] and the normalised input is the sum of the slabs (added in slab order) */
 int ct_layernorm128_f32(const float *x, const float *gamma, const float *beta, const float *residual,

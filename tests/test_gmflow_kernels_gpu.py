@@ -385,9 +385,10 @@ def test_linear_ws16_wide_dynamic_range(hip):
     bound = F.linear(xk.double().abs(), wk.double().abs()) + 1e-300
     assert ((out.sum(0).cpu().double() - ref).abs() / bound).max().item() < 1e-6
     lib, p = hip.lib(), out.data_ptr()
-    assert lib.ct_linear_ws16_f32(p, None, 256, p, 0, None, p, 64, 256, 96, 0, None) == -1      # n % 128
-    assert lib.ct_linear_ws16_f32(p, None, 1024, p, 0, None, p, 64, 1024, 128, 6, None) == -1   # no activation on partial slabs
-    assert lib.ct_linear_ws16_f32(p, None, 256, p, 0, None, p, 0, 256, 128, 0, None) == 0       # no tokens
+    assert lib.ct_linear_ws16_f32(p, None, 256, p, 0, None, p, 64, 256, 96, 0, None, None, None, None) == -1      # n % 128
+    assert lib.ct_linear_ws16_f32(p, None, 1024, p, 0, None, p, 64, 1024, 128, 6, None, None, None, None) == -1   # no activation on partial slabs
+    assert lib.ct_linear_ws16_f32(p, None, 256, p, 0, None, p, 0, 256, 128, 0, None, None, None, None) == 0       # no tokens
+    assert lib.ct_linear_ws16_f32(p, None, 256, p, 0, None, p, 64, 256, 128, 0, p, p, None, None) == -1   # LayerNorm epilogue: k = n = 128 only
 
 
 @pytest.mark.parametrize("count,t,bias", [(3, 4096, False), (2, 5001, True), (1, 4100, False), (4, 8192, True)])
@@ -405,3 +406,19 @@ def test_linear_tokens_multi(hip, count, t, bias):
         assert ((o.double().cpu() - ref).abs() / bound).max().item() < 1e-6
     small = hip.linear_tokens_multi(x.cuda()[..., :64, :].contiguous(), ws, bs)       # few tokens: the separate kernels
     assert len(small) == count and small[0].shape[-1] == 128
+
+
+@pytest.mark.parametrize("t,res,bias", [(4096, True, False), (5003, False, True), (64, True, True)])
+def test_linear_layernorm128(hip, t, res, bias):
+    """merge projection + LayerNorm (+ skip) in one launch (the LayerNorm epilogue of ct_linear_ws16_f32) == the two kernels"""
+    x, w = rnd(t, 128) * 3, (rnd(128, 128) / 128 ** 0.5).cuda()
+    b = rnd(128) if bias else None
+    g, be, r = rnd(128), rnd(128), rnd(t, 128) if res else None
+    lin = F.linear(x.double(), w.double().cpu(), b.double() if bias else None)
+    ref = F.layer_norm(lin, (128,), g.double(), be.double()) + (r.double() if res else 0)
+    out = hip.linear_layernorm128(x.cuda(), w, b.cuda() if bias else None, g.cuda(), be.cuda(), residual=r.cuda() if res else None)
+    close(out, ref, "linear + LayerNorm", atol=2e-5, rtol=2e-5)
+    xs = x * torch.pow(2.0, torch.randint(-12, 13, (t, 1), generator=G).float())     # LayerNorm is scale invariant per token: so is the error
+    lin = F.linear(xs.double(), w.double().cpu())
+    ref = F.layer_norm(lin, (128,), g.double(), be.double())
+    close(hip.linear_layernorm128(xs.cuda(), w, None, g.cuda(), be.cuda()), ref, "tokens of any magnitude", atol=3e-5, rtol=3e-5)
