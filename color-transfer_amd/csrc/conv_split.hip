@@ -510,6 +510,17 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
                                         v.z = split_act<GEN>(v.z, a.act); v.w = split_act<GEN>(v.w, a.act);
                                     }
                                     if (!a.res_pre) { v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+                                    if (a.post_op) {
+                                        const size_t po = (size_t)n * a.out_bstride + (size_t)grp * COUTP * plane + o;
+                                        const float4 q1 = *reinterpret_cast<const float4 *>(a.p1 + po);
+                                        if (a.post_op == 1) {
+                                            v.x *= q1.x; v.y *= q1.y; v.z *= q1.z; v.w *= q1.w;
+                                        } else {
+                                            const float4 q2 = *reinterpret_cast<const float4 *>(a.p2 + po);
+                                            v.x = (1.0f - q1.x) * q2.x + q1.x * v.x; v.y = (1.0f - q1.y) * q2.y + q1.y * v.y;
+                                            v.z = (1.0f - q1.z) * q2.z + q1.z * v.z; v.w = (1.0f - q1.w) * q2.w + q1.w * v.w;
+                                        }
+                                    }
                                     if (a.clamp) {
                                         v.x = fminf(fmaxf(v.x, 0.f), 1.f); v.y = fminf(fmaxf(v.y, 0.f), 1.f);
                                         v.z = fminf(fmaxf(v.z, 0.f), 1.f); v.w = fminf(fmaxf(v.w, 0.f), 1.f);
@@ -631,7 +642,7 @@ int conv_split(const ConvArgs &a, int N, int kh, int kw, bool gen, hipStream_t s
     if (!vec) return 1;
     if (a.rows_channels > 0 && ((a.rows_channels & 3) || (a.rows_c0 & 3) || a.rows_c0 + a.cout > a.rows_channels || a.residual || a.clamp))
         return CT_E_BADARG;
-    if (kh == 3 && kw == 3 && a.rows_channels == 0 && !a.res_pre) {
+    if (kh == 3 && kw == 3 && a.rows_channels == 0 && !a.res_pre && !a.post_op) {
         const int rc = conv_ws(a, N, gen, s);
         if (rc != 1) return rc;
     }
@@ -661,8 +672,10 @@ extern "C" {
 int ct_conv2d_split_f32(const float *in, const float *in2, int cin1, const float *in3, int cin2, const void *wp_split, const float *bias,
                         const float *residual, float *out, int n, int cin, int cout, int h, int w, int kh, int kw, long long in_bstride,
                         long long in2_bstride, long long in3_bstride, long long out_bstride, long long res_bstride, int act, int clamp,
-                        int res_pre_act, int f16, int w_exp, void *stream) {
+                        int res_pre_act, int f16, int w_exp, int post_op, const float *p1, const float *p2, void *stream) {
     if (!in || !wp_split || !bias || !out || n < 0 || cin < 1 || cout < 1 || h < 0 || w < 0 || act < 0 || act > 5) return CT_E_BADARG;
+    if (post_op < 0 || post_op > 2 || (post_op && (!f16 || !p1 || (post_op == 2 && !p2)))) return CT_E_BADARG;
+    if (post_op && ((reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15)) return CT_E_ALIGN;
     if (in2 && (cin1 < 16 || cin1 >= cin || (cin1 % 16))) return CT_E_BADARG;
     if (in3 && (!in2 || cin2 <= cin1 || cin2 >= cin || (cin2 % 16))) return CT_E_BADARG;
     if (n == 0 || h == 0 || w == 0) return CT_OK;
@@ -675,6 +688,7 @@ int ct_conv2d_split_f32(const float *in, const float *in2, int cin1, const float
     a.act = act; a.clamp = clamp; a.groups = (cout + 63) / 64; a.prof = nullptr;
     a.res_pre = (residual && res_pre_act) ? 1 : 0;
     a.f16 = f16 ? 1 : 0; a.w_exp = f16 ? w_exp : 0;
+    a.post_op = post_op; a.p1 = p1; a.p2 = p2;
     const int rc = ct::conv_split(a, n, kh, kw, true, (hipStream_t)stream);
     return rc == 1 ? CT_E_BADARG : rc;
 }

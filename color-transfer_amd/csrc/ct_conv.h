@@ -26,6 +26,9 @@ struct ConvArgs {
     int f16 = 0;                // conv_ws only: 1 = two fp16 pieces (weights scaled by 2^w_exp), 0 = three bf16 pieces
     int w_exp = 0;
     int rows_channels = 0;      // split kernel only: > 0 = `out` is a token-rows tensor [N*H, W, rows_channels] and the result goes to its
+    int post_op = 0;            // split kernel, F16 form, NCHW output: 1 = result * p1; 2 = (1 - p1) * p2 + p1 * result (the GRU gate of
+    const float *p1 = nullptr;  // reg_refine.py:46-55: p1 = z, p2 = h), applied after the activation; p1 / p2 laid out like `out`
+    const float *p2 = nullptr;
     int res_pre = 0;            // split kernel only: 1 = `residual` is added BEFORE the activation (a pre-computed partial convolution)
     int rows_c0 = 0;            // channels rows_c0 .. rows_c0 + cout (multiples of 4); no residual / clamp in this mode
 };

@@ -523,7 +523,8 @@ SIGNATURES.update({
                                _c_ll, _c_int, _c_int, _c_p]),
     "ct_pam_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
     "ct_conv2d_split_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int,
-                                     _c_int, _c_int, _c_ll, _c_ll, _c_ll, _c_ll, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
+                                     _c_int, _c_int, _c_ll, _c_ll, _c_ll, _c_ll, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p,
+                                     _c_p, _c_p]),
     "ct_pam_attend_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "ct_pam_valid_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_sz, _c_p]),
 })
@@ -623,7 +624,7 @@ def _split_ok(x, out, residual, kh, kw, stride, ph, pw):
     return True
 
 
-def _conv_split(x, split, cout, kh, kw, act, residual, clamp, out, x2=None, x3=None, res_pre=False):
+def _conv_split(x, split, cout, kh, kw, act, residual, clamp, out, x2=None, x3=None, res_pre=False, post=None):
     ws, b64 = split[0], split[1]
     f16, w_exp = 0, 0
     if _ws16 and len(split) > 2 and split[2] is not None:      # two fp16 pieces (default): the fp16 image replaces the bf16 one
@@ -632,7 +633,10 @@ def _conv_split(x, split, cout, kh, kw, act, residual, clamp, out, x2=None, x3=N
     cin2 = cin1 + (x2.shape[1] if x2 is not None else 0)
     cin = cin2 + (x3.shape[1] if x3 is not None else 0)
     rs = _nchw_bstride(residual) if residual is not None else 0
-    if x2 is None and not res_pre and _ws16_ok(x, split, kh, kw):
+    post_op, p1, p2 = (0, None, None) if post is None else post
+    if post_op and not f16:
+        raise CtHipError("a fused post-op needs the fp16 form of the split kernel")
+    if x2 is None and not res_pre and not post_op and _ws16_ok(x, split, kh, kw):
         w16, w_exp = split[2]
         check(lib().ct_conv3x3_ws16_f32(_ptr(x), _ptr(w16), int(w_exp), _ptr(b64), _opt(residual), _ptr(out), n, cin, cout, h, w,
                                         _nchw_bstride(x), _nchw_bstride(out), rs, int(act), int(bool(clamp)), _stream()))
@@ -640,7 +644,7 @@ def _conv_split(x, split, cout, kh, kw, act, residual, clamp, out, x2=None, x3=N
     check(lib().ct_conv2d_split_f32(_ptr(x), _opt(x2), cin1, _opt(x3), cin2, _ptr(ws), _ptr(b64), _opt(residual), _ptr(out), n, cin,
                                     cout, h, w, kh, kw, _nchw_bstride(x), _nchw_bstride(x2) if x2 is not None else 0,
                                     _nchw_bstride(x3) if x3 is not None else 0, _nchw_bstride(out), rs, int(act), int(bool(clamp)),
-                                    int(bool(res_pre)), f16, int(w_exp), _stream()))
+                                    int(bool(res_pre)), f16, int(w_exp), int(post_op), _opt(p1), _opt(p2), _stream()))
     return out
 
 
@@ -824,11 +828,12 @@ def pack_gconv_weight(weight, bias):
     return wp, b
 
 
-def gconv2d(x, wp, bias, cout, ksize, stride=1, padding=0, act=ACT_NONE, out=None, x2=None, residual=None, addend=None):
+def gconv2d(x, wp, bias, cout, ksize, stride=1, padding=0, act=ACT_NONE, out=None, x2=None, residual=None, addend=None, post=None):
     """x2: optional second input tensor whose channels follow x's (torch.cat([x, x2], 1) without the copy when the
     split-bf16 kernel takes the convolution; otherwise the concatenation is materialised here).  residual: added to the
     result (act must be ACT_NONE: MBConvBlock's identity skip).  addend: a tensor of the output's shape added BEFORE the
-    activation (a pre-computed part of the convolution); split kernel only -- CtHipError otherwise."""
+    activation (a pre-computed part of the convolution); split kernel only -- CtHipError otherwise.  post (with addend, fp16 form):
+    (1, p1, None) = the activated result times p1; (2, z, h) = (1 - z) * h + z * result -- the GRU's two elementwise steps."""
     kh, kw = (ksize, ksize) if isinstance(ksize, int) else ksize
     ph, pw = (padding, padding) if isinstance(padding, int) else padding
     if residual is not None and (act != ACT_NONE or x2 is not None or addend is not None):
@@ -843,7 +848,12 @@ def gconv2d(x, wp, bias, cout, ksize, stride=1, padding=0, act=ACT_NONE, out=Non
               (x2 is None or (c1 % 16 == 0 and x2.data_ptr() % 16 == 0 and x2.stride(0) % 4 == 0)))
         if not ok:
             raise CtHipError("gconv2d: an addend needs the split kernel (conv mode 'split', stride 1, 'same' padding, W % 4 == 0)")
-        return _conv_split(x, split, cout, kh, kw, act, addend, False, out, x2=x2, res_pre=True)
+        if post is not None:
+            if not _ws16 or any(t is not None and (t.shape != out.shape or not t.is_contiguous() or t.dtype != torch.float32) for t in post[1:]):
+                raise CtHipError("gconv2d: post-op operands must be contiguous float32 tensors of the output's shape (fp16 form only)")
+            if not out.is_contiguous():
+                raise CtHipError("gconv2d: a post-op needs a contiguous output")
+        return _conv_split(x, split, cout, kh, kw, act, addend, False, out, x2=x2, res_pre=True, post=post)
     if x2 is not None:
         split = getattr(wp, "_ct_split", None)
         n, c1, h, w = x.shape

@@ -350,17 +350,23 @@ class GMFlow(nn.Module):
         if pre is not None:
             parts, mot = self._gru_parts(), x[:, 128:]
 
-            def part(name, a, act, x2=None):
+            fuse = ct_hip.conv_ws16()       # the fp16 form's epilogue also does the GRU's elementwise steps: r * h and the gate
+
+            def part(name, a, act, x2=None, post=None):
                 conv = getattr(gru, name)
                 wp, bp = parts[name][1]
-                return ct_hip.gconv2d(a, wp, bp, 128, tuple(conv.kernel_size), 1, tuple(conv.padding), act=act, x2=x2, addend=pre[name])
+                return ct_hip.gconv2d(a, wp, bp, 128, tuple(conv.kernel_size), 1, tuple(conv.padding), act=act, x2=x2, addend=pre[name],
+                                      post=post)
             for suf in ("1", "2"):
-                if suf == "1":
-                    z, r = part("convz1", mot, ACT_SIGMOID), part("convr1", mot, ACT_SIGMOID)
+                hin = (mot, None) if suf == "1" else (h, mot)
+                z = part("convz" + suf, hin[0], ACT_SIGMOID, x2=hin[1])
+                if fuse:
+                    rh = part("convr" + suf, hin[0], ACT_SIGMOID, x2=hin[1], post=(1, h, None))          # sigmoid(.) * h
+                    h = part("convq" + suf, rh, ACT_TANH, x2=mot, post=(2, z, h))                        # (1 - z) h + z tanh(.)
                 else:
-                    z, r = part("convz2", h, ACT_SIGMOID, x2=mot), part("convr2", h, ACT_SIGMOID, x2=mot)
-                q = part("convq" + suf, ct_hip.eltwise(1, r, h), ACT_TANH, x2=mot)
-                h = ct_hip.eltwise(2, z, h, q)
+                    r = part("convr" + suf, hin[0], ACT_SIGMOID, x2=hin[1])
+                    q = part("convq" + suf, ct_hip.eltwise(1, r, h), ACT_TANH, x2=mot)
+                    h = ct_hip.eltwise(2, z, h, q)
         else:
             for suf in ("1", "2"):
                 z = _conv(getattr(gru, "convz" + suf), h, ACT_SIGMOID, x2=x)

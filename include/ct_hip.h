@@ -242,12 +242,15 @@ int ct_conv2d_f32(const float *in, const float *wp, const float *bias, const flo
  * f16 != 0: wp_split is the TWO-piece fp16 image of weight * 2^w_exp instead (ct_hip.pack_conv_weight_split16: same index order
  * with [piece hi,lo]; three v_mfma_f32_32x32x16_f16 per product, 2^-22 relative dropped; every staged 16-channel input tile
  * carries a running power-of-two scale per output tile, so any finite float32 input is in range) -- half the matrix work.
+ * post_op (f16 form only; p1 / p2 dense tensors with out's strides): 1 = the activated result times p1 (the GRU's r * h,
+ * reg_refine.py:50), 2 = (1 - p1) * p2 + p1 * result (its gate h = (1 - z) h + z q, reg_refine.py:47,55), before the clamp.
  * residual: added after the activation (ResB skip), or -- res_pre_act != 0 -- BEFORE it: a pre-computed partial convolution
  * (the SepConvGRU's loop-invariant `inp` channels, reg_refine.py:25-55: conv(cat([h, inp, motion])) = conv_inp(inp) + conv(rest)). */
 int ct_conv2d_split_f32(const float *in, const float *in2, int cin1, const float *in3, int cin2, const void *wp_split,
                         const float *bias, const float *residual, float *out, int n, int cin, int cout, int h, int w, int kh,
                         int kw, long long in_bstride, long long in2_bstride, long long in3_bstride, long long out_bstride,
-                        long long res_bstride, int act, int clamp, int res_pre_act, int f16, int w_exp, void *stream);
+                        long long res_bstride, int act, int clamp, int res_pre_act, int f16, int w_exp, int post_op,
+                        const float *p1, const float *p2, void *stream);
 
 /* ct_conv2d_split_f32 of one input tensor with the result stored as TOKEN ROWS: out_rows[(n*h + y)*w + x][rows_c0 + co] of a
  * [n*h, w, rows_channels] tensor (rows_channels, rows_c0, cout multiples of 4; rows_c0 + cout <= rows_channels).  The query / key /

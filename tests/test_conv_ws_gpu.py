@@ -223,3 +223,23 @@ def test_conv_split16_wide_dynamic_range(hip, kh, kw):
     finally:
         hip.set_conv_ws16(True)
     assert ((old - lin).abs() / (1e-6 * bound + 1e-7 * b.abs().max().item())).max().item() < 1.0
+
+
+def test_conv_post_ops_equal_the_elementwise_kernels(hip):
+    """the GRU's elementwise steps in the convolution epilogue (post_op of ct_conv2d_split_f32: sigmoid(.) * h and
+    (1 - z) h + z tanh(.)) == the convolution followed by the elementwise kernel, bitwise (same float32 expressions)"""
+    n, cin, cout, h, w = 2, 128, 128, 24, 40
+    x, hid, z, add = rnd(n, cin, h, w), rnd(n, cout, h, w), torch.rand(n, cout, h, w, generator=G), rnd(n, cout, h, w)
+    wt, b = rnd(cout, cin, 1, 5) / (cin * 5) ** 0.5, rnd(cout)
+    wp, bp = hip.pack_gconv_weight(wt.cuda(), b.cuda())
+    xc, hc, zc, ac = x.cuda(), hid.cuda(), z.cuda(), add.cuda()
+    r = hip.gconv2d(xc, wp, bp, cout, (1, 5), 1, (0, 2), act=3, addend=ac)
+    rh = hip.gconv2d(xc, wp, bp, cout, (1, 5), 1, (0, 2), act=3, addend=ac, post=(1, hc, None))
+    assert torch.equal(rh, hip.eltwise(1, r, hc))
+    q = hip.gconv2d(xc, wp, bp, cout, (1, 5), 1, (0, 2), act=4, addend=ac)
+    hn = hip.gconv2d(xc, wp, bp, cout, (1, 5), 1, (0, 2), act=4, addend=ac, post=(2, zc, hc))
+    assert torch.equal(hn, hip.eltwise(2, zc, hc, q))
+    ref = (1 - z.double()) * hid.double() + z.double() * torch.tanh(F.conv2d(x.double(), wt.double(), b.double(), padding=(0, 2)) + add.double())
+    assert (hn.double().cpu() - ref).abs().max().item() < 3e-6
+    with pytest.raises(hip.CtHipError):
+        hip.gconv2d(xc, wp, bp, cout, (1, 5), 1, (0, 2), act=4, addend=ac, post=(2, zc, hc[:, :64]))
