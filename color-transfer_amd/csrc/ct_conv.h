@@ -33,6 +33,20 @@ struct ConvArgs {
     int rows_c0 = 0;            // channels rows_c0 .. rows_c0 + cout (multiples of 4); no residual / clamp in this mode
 };
 
+struct GConvArgs {
+    const float *in, *wp, *bias;   // wp: [coutp/64][kh*kw][cin_pairs][2][64], coutp = 64*ceil(cout/64); bias padded to coutp (or null)
+    float *out;
+    int cin, cout, coutp, H, W, Ho, Wo, KH, KW, stride, padH, padW;
+    long long in_bstride, out_bstride;
+    int act;      // 0 none, 1 LeakyReLU(0.01), 2 ReLU, 3 sigmoid, 4 tanh, 5 swish
+    int cchunk;   // input channels staged per LDS pass (even)
+};
+
+// conv_direct.hip: float32 VALU convolutions for the shapes an implicit-GEMM tile wastes (returns 1 if the shape is not theirs):
+//   cout <= 4, kernel 3x3 / 1x1, stride 1, "same" padding (GMFlow's flow head: 256 -> 2), and
+//   cin <= 3, kernel <= 7x7, stride 1 or 2 (its 7x7 stem 3 -> 64 and the motion encoder's 7x7 on the 2-channel flow)
+int conv_direct(const GConvArgs &a, int N, hipStream_t s);
+
 // cnn.hip: stride-1, padding k/2, kernel 3x3 / 1x1 / 1x5 / 5x1, weights packed [group][tap][cin_pair][2][64];
 // returns CT_OK / an error, or 1 if (kh, kw) has no LDS-tiled kernel
 int conv_fast(const ConvArgs &a, int N, int kh, int kw, hipStream_t s);

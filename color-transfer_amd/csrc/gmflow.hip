@@ -26,15 +26,6 @@ typedef float f32x16g __attribute__((ext_vector_type(16)));
 // Generic convolution: M = 64 output channels per workgroup, N = 4 rows x 32 columns of output pixels,
 // K = (kh*kw) taps x input channels staged through LDS in chunks.
 // =================================================================================================
-struct GConvArgs {
-    const float *in, *wp, *bias;   // wp: [coutp/64][kh*kw][cin_pairs][2][64], coutp = 64*ceil(cout/64); bias padded to coutp (or null)
-    float *out;
-    int cin, cout, coutp, H, W, Ho, Wo, KH, KW, stride, padH, padW;
-    long long in_bstride, out_bstride;
-    int act;      // 0 none, 1 LeakyReLU(0.01), 2 ReLU, 3 sigmoid, 4 tanh, 5 swish
-    int cchunk;   // input channels staged per LDS pass (even)
-};
-
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case 1: return v > 0.f ? v : 0.01f * v;
@@ -1638,6 +1629,10 @@ int ct_gconv2d_f32(const float *in, const float *wp, const float *bias, float *o
     a.Ho = (h + 2 * pad_h - kh) / stride + 1; a.Wo = (w + 2 * pad_w - kw) / stride + 1;
     if (a.Ho < 1 || a.Wo < 1) return CT_E_BADARG;
     a.in_bstride = in_bstride; a.out_bstride = out_bstride; a.act = act;
+    {
+        const int rc = ct::conv_direct(a, n, (hipStream_t)stream);      // the shapes an implicit-GEMM tile wastes (conv_direct.hip)
+        if (rc != 1) return rc;
+    }
     if (stride == 1 && pad_h == kh / 2 && pad_w == kw / 2 && (kh & 1) && (kw & 1) && bias) {
         // stride-1 "same" convolution: the LDS-tiled persistent kernel of cnn.hip (same weight layout)
         ct::ConvArgs f;

@@ -868,7 +868,8 @@ def gconv2d(x, wp, bias, cout, ksize, stride=1, padding=0, act=ACT_NONE, out=Non
     if out is None:
         out = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device)
     split = getattr(wp, "_ct_split", None)
-    if split is not None and bias is not None and _split_ok(x, out, residual, kh, kw, stride, ph, pw):
+    # cout <= 4 (the flow head's 256 -> 2): ct_gconv2d_f32's direct kernel instead of a 64-output-channel tile
+    if split is not None and bias is not None and (cout > 4 or residual is not None) and _split_ok(x, out, residual, kh, kw, stride, ph, pw):
         return _conv_split(x, split, cout, kh, kw, act, residual, False, out)
     check(lib().ct_gconv2d_f32(_ptr(x), _ptr(wp), _opt(bias), _ptr(out), n, cin, cout, h, w, kh, kw, stride, ph, pw,
                                _nchw_bstride(x), _nchw_bstride(out), int(act), _stream()))

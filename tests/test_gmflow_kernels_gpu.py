@@ -35,7 +35,10 @@ def rnd(*shape):
     (1, 256, 126, 8, 36, 3, 3, 1, 1, 1), (1, 256, 2, 8, 36, 3, 3, 1, 1, 1), (1, 256, 144, 8, 36, 1, 1, 1, 0, 0),
     # multi-tile / multi-group geometries of the LDS-tiled stride-1 path (persistent schedule, 16-byte I/O)
     (2, 96, 96, 40, 72, 3, 3, 1, 1, 1), (1, 130, 256, 24, 64, 3, 3, 1, 1, 1), (3, 384, 128, 20, 68, 1, 5, 1, 0, 2),
-    (3, 384, 128, 21, 68, 5, 1, 1, 2, 0), (2, 64, 192, 17, 100, 1, 1, 1, 0, 0)])
+    (3, 384, 128, 21, 68, 5, 1, 1, 2, 0), (2, 64, 192, 17, 100, 1, 1, 1, 0, 0),
+    # the direct VALU kernels (csrc/conv_direct.hip): cout <= 4, and cin <= 3 with a 7x7 kernel; several tiles, ragged edges
+    (2, 256, 2, 37, 70, 3, 3, 1, 1, 1), (1, 61, 3, 20, 45, 3, 3, 1, 1, 1), (1, 16, 4, 9, 33, 1, 1, 1, 0, 0),
+    (2, 2, 128, 40, 72, 7, 7, 1, 3, 3), (1, 3, 64, 64, 131, 7, 7, 2, 3, 3)])
 def test_gconv(hip, cfg, conv_mode):
     n, cin, cout, h, w, kh, kw, s, ph, pw = cfg
     x, wt, b = rnd(n, cin, h, w), rnd(cout, cin, kh, kw) / (cin * kh * kw) ** 0.5, rnd(cout)
