@@ -115,6 +115,9 @@ __global__ __launch_bounds__(512, 1) void linear_ws16_kernel(Ws16Args a) {
     float4 raw[4][4];
     uint4 fb[2][2][2];                             // B fragments [chunk parity][K step][piece]
     auto fetch = [&](const float4 *p, int c, float4 (&r)[4]) {
+#ifdef CT_W16_ABL_NOLOAD
+        if (tile != t_begin + wave) return;
+#endif
 #pragma unroll
         for (int q = 0; q < 4; ++q) r[q] = p[4 * c + q];
     };
@@ -143,7 +146,15 @@ __global__ __launch_bounds__(512, 1) void linear_ws16_kernel(Ws16Args a) {
     int e_cur = chunk_max(raw[0]), e_nxt = e_cur;  // per lane (= token): domain of its accumulators / scale of the fragments converted last
     split_x(raw[0], pow2i_w(e_cur), fb[0]);
     const uint4 *wb = Ws + hl * 128 + nl;
+    uint4 wf0[4][2], wf1[4][2];                    // W fragments of the even / odd K steps
+    auto load_w = [&](int ks, uint4 (&wf)[4][2]) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[j][p] = wb[((p * KS + ks) * 2) * 128 + 32 * j];
+    };
     float4 *stg = reinterpret_cast<float4 *>(Ws + kW16Img) + wave * (32 * 8);      // per-wave output transpose, 4 KiB
+    load_w(0, wf0);
     for (; tile < t_end; tile += 8) {
         const int next = tile + 8;
         const float4 *xn = row_ptr(next < t_end ? next : tile);
@@ -152,6 +163,16 @@ __global__ __launch_bounds__(512, 1) void linear_ws16_kernel(Ws16Args a) {
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        auto mfma_step = [&](const uint4 (&wf)[4][2], const uint4 (&xf)[2]) {
+            const f16x8w xh = __builtin_bit_cast(f16x8w, xf[0]), xl = __builtin_bit_cast(f16x8w, xf[1]);
+            // small terms first; the four accumulators take turns, so no MFMA waits for the one issued just before it
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8w, wf[j][1]), xh, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8w, wf[j][0]), xl, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8w, wf[j][0]), xh, acc[j], 0, 0, 0);
+        };
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             // raw[(c + 1) & 3] holds chunk c+1 (of this tile, or chunk 0 of the next): converted under the MFMAs of chunk c;
@@ -161,27 +182,18 @@ __global__ __launch_bounds__(512, 1) void linear_ws16_kernel(Ws16Args a) {
             const int e_chunk = chunk_max(raw[(c + 1) & 3]);
             e_nxt = (c == NCH - 1) ? e_chunk : min(e_cur, e_chunk);       // a new tile starts its own running scale
             const float sc = pow2i_w(e_nxt);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                uint4 wf[4][2];
-#pragma unroll
-                for (int p = 0; p < 2; ++p)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) wf[j][p] = wb[((p * KS + 2 * c + s) * 2) * 128 + 32 * j];
-                const f16x8w xh = __builtin_bit_cast(f16x8w, fb[c & 1][s][0]), xl = __builtin_bit_cast(f16x8w, fb[c & 1][s][1]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f16x8w wh = __builtin_bit_cast(f16x8w, wf[j][0]), wl = __builtin_bit_cast(f16x8w, wf[j][1]);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc[j], 0, 0, 0);
-                }
-            }
+            // W fragments double buffered in registers: the eight LDS reads of K step ks + 1 are issued under the MFMAs of step ks
+            // (left to itself the compiler keeps ONE fragment register and waits out the LDS latency before every MFMA pair)
+            load_w(2 * c + 1, wf1);
+            mfma_step(wf0, fb[c & 1][0]);
+            load_w((2 * c + 2) % KS, wf0);
+            mfma_step(wf1, fb[c & 1][1]);
             split_x(raw[(c + 1) & 3], sc, fb[(c + 1) & 1]);
 #pragma unroll
-            for (int q = 0; q < 12; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            for (int q = 0; q < 8; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // two of the sixteen fragment reads
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);      // three of the 24 MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);      // conversion of the next chunk
             }
             if (c < NCH - 1 && __builtin_amdgcn_ballot_w64(e_nxt != e_cur) != 0) {   // a token's running scale dropped: new domain
                 const float rs = __builtin_amdgcn_ldexpf(1.0f, e_nxt - e_cur);
@@ -237,7 +249,9 @@ __global__ __launch_bounds__(512, 1) void linear_ws16_kernel(Ws16Args a) {
                         const float4 b4 = *reinterpret_cast<const float4 *>(bias + 32 * j + 8 * g + 4 * hl);
                         v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
                     }
+#ifndef CT_W16_ABL_NOGELU
                     if (a.act == 6) { v.x = gelu_w(v.x); v.y = gelu_w(v.y); v.z = gelu_w(v.z); v.w = gelu_w(v.w); }
+#endif
                 }
                 stg[nl * 8 + ((2 * g + hl) ^ (nl & 7))] = v;
             }
@@ -246,7 +260,11 @@ __global__ __launch_bounds__(512, 1) void linear_ws16_kernel(Ws16Args a) {
             for (int q = 0; q < 4; ++q) {
                 const int tk = (lane >> 3) + 8 * q, c4 = lane & 7;
                 float4 v = stg[tk * 8 + (c4 ^ (tk & 7))];
+#ifdef CT_W16_ABL_NOSTORE
+                if (tbase + tk < a.T && v.x == 123.456f) {
+#else
                 if (tbase + tk < a.T) {
+#endif
                     if (NCH == 4 && a.ln_res) {
                         const float4 r4 = *reinterpret_cast<const float4 *>(a.ln_res + (tbase + tk) * 128 + 32 * j + 4 * c4);
                         v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
