@@ -460,76 +460,88 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
                 if (a.rows_channels > 0) {
                     float *__restrict__ orow = a.out + (size_t)n * plane * a.rows_channels + a.rows_c0 + grp * COUTP;
                     const int x = tx * kSpTW + nl;
-#pragma unroll
-                    for (int q = 0; q < RPW; ++q) {
+                    static_assert(RPW == 2 && MT == 2, "block select below");
+#pragma unroll 1
+                    for (int qm = 0; qm < RPW * MT; ++qm) {            // rolled like the NCHW form below (code size)
+                        const int q = qm >> 1, m = qm & 1;
                         const int y = ty * kSpTH + wave * RPW + q;
+                        f32x16s blk;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            blk[r] = qm == 0 ? acc[0][0][r] : qm == 1 ? acc[0][1][r] : qm == 2 ? acc[1][0][r] : acc[1][1][r];
                         if (y < a.H && x < a.W) {
                             float *__restrict__ op = orow + (size_t)(y * a.W + x) * a.rows_channels;
-#pragma unroll
-                            for (int m = 0; m < MT; ++m) {
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    const int co = m * 32 + 8 * j + 4 * hl;
-                                    const float4 b4 = *reinterpret_cast<const float4 *>(bias_g + co);
-                                    float4 v = make_float4(__builtin_amdgcn_ldexpf(acc[q][m][4 * j], un) + b4.x,
-                                                           __builtin_amdgcn_ldexpf(acc[q][m][4 * j + 1], un) + b4.y,
-                                                           __builtin_amdgcn_ldexpf(acc[q][m][4 * j + 2], un) + b4.z,
-                                                           __builtin_amdgcn_ldexpf(acc[q][m][4 * j + 3], un) + b4.w);
-                                    if (a.act) {
-                                        v.x = split_act<GEN>(v.x, a.act); v.y = split_act<GEN>(v.y, a.act);
-                                        v.z = split_act<GEN>(v.z, a.act); v.w = split_act<GEN>(v.w, a.act);
-                                    }
-                                    if (full || co < cout_g) *reinterpret_cast<float4 *>(op + co) = v;
+#pragma unroll 1
+                            for (int jj = 0; jj < 4; ++jj) {
+                                const int co = m * 32 + 8 * jj + 4 * hl;
+                                const float4 b4 = *reinterpret_cast<const float4 *>(bias_g + co);
+                                const float r0 = jj == 0 ? blk[0] : jj == 1 ? blk[4] : jj == 2 ? blk[8] : blk[12];
+                                const float r1 = jj == 0 ? blk[1] : jj == 1 ? blk[5] : jj == 2 ? blk[9] : blk[13];
+                                const float r2 = jj == 0 ? blk[2] : jj == 1 ? blk[6] : jj == 2 ? blk[10] : blk[14];
+                                const float r3 = jj == 0 ? blk[3] : jj == 1 ? blk[7] : jj == 2 ? blk[11] : blk[15];
+                                float4 v = make_float4(__builtin_amdgcn_ldexpf(r0, un) + b4.x, __builtin_amdgcn_ldexpf(r1, un) + b4.y,
+                                                       __builtin_amdgcn_ldexpf(r2, un) + b4.z, __builtin_amdgcn_ldexpf(r3, un) + b4.w);
+                                if (a.act) {
+                                    v.x = split_act<GEN>(v.x, a.act); v.y = split_act<GEN>(v.y, a.act);
+                                    v.z = split_act<GEN>(v.z, a.act); v.w = split_act<GEN>(v.w, a.act);
                                 }
+                                if (full || co < cout_g) *reinterpret_cast<float4 *>(op + co) = v;
                             }
                         }
                     }
                 } else {
-#pragma unroll
-                    for (int q = 0; q < RPW; ++q) {
+                    // ROLLED over the (row, 32-channel tile) blocks and over the four 8-channel groups of a block: the generic
+                    // activation (expf / tanhf inline) was instantiated 64 times here -- 100 KB of code streaming through the 64 KB
+                    // instruction cache once per output tile, evicting the tap loop of this and the neighbouring workgroups.  The
+                    // block's accumulator is picked with selects (the registers cannot be indexed dynamically).
+                    static_assert(RPW == 2 && MT == 2, "block select below");
+#pragma unroll 1
+                    for (int qm = 0; qm < RPW * MT; ++qm) {
+                        const int q = qm >> 1, m = qm & 1;
                         const int y = ty * kSpTH + wave * RPW + q;
+                        f32x16s blk;
 #pragma unroll
-                        for (int m = 0; m < MT; ++m) {
+                        for (int r = 0; r < 16; ++r)
+                            blk[r] = qm == 0 ? acc[0][0][r] : qm == 1 ? acc[0][1][r] : qm == 2 ? acc[1][0][r] : acc[1][1][r];
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int ch = (r & 3) + 8 * (r >> 2) + 4 * hl;
-                                stg[ch * 32 + nl] = __builtin_amdgcn_ldexpf(acc[q][m][r], un) + bias_g[m * 32 + ch];
-                            }
-                            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const int co = m * 32 + (lane >> 3) + 8 * j;
-                                float4 v = *reinterpret_cast<const float4 *>(stg + ((lane >> 3) + 8 * j) * 32 + 4 * (lane & 7));
-                                if (y < a.H && x4 < a.W && (full || co < cout_g)) {
-                                    const unsigned int o = (unsigned int)co * uplane + (unsigned int)(y * a.W + x4);
-                                    float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
-                                    if (res) rr = *reinterpret_cast<const float4 *>(res + o);
-                                    if (a.res_pre) { v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
-                                    if (a.act) {
-                                        v.x = split_act<GEN>(v.x, a.act); v.y = split_act<GEN>(v.y, a.act);
-                                        v.z = split_act<GEN>(v.z, a.act); v.w = split_act<GEN>(v.w, a.act);
-                                    }
-                                    if (!a.res_pre) { v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
-                                    if (a.post_op) {
-                                        const size_t po = (size_t)n * a.out_bstride + (size_t)grp * COUTP * plane + o;
-                                        const float4 q1 = *reinterpret_cast<const float4 *>(a.p1 + po);
-                                        if (a.post_op == 1) {
-                                            v.x *= q1.x; v.y *= q1.y; v.z *= q1.z; v.w *= q1.w;
-                                        } else {
-                                            const float4 q2 = *reinterpret_cast<const float4 *>(a.p2 + po);
-                                            v.x = (1.0f - q1.x) * q2.x + q1.x * v.x; v.y = (1.0f - q1.y) * q2.y + q1.y * v.y;
-                                            v.z = (1.0f - q1.z) * q2.z + q1.z * v.z; v.w = (1.0f - q1.w) * q2.w + q1.w * v.w;
-                                        }
-                                    }
-                                    if (a.clamp) {
-                                        v.x = fminf(fmaxf(v.x, 0.f), 1.f); v.y = fminf(fmaxf(v.y, 0.f), 1.f);
-                                        v.z = fminf(fmaxf(v.z, 0.f), 1.f); v.w = fminf(fmaxf(v.w, 0.f), 1.f);
-                                    }
-                                    *reinterpret_cast<float4 *>(out + o) = v;
-                                }
-                            }
-                            __builtin_amdgcn_wave_barrier();
+                        for (int r = 0; r < 16; ++r) {
+                            const int ch = (r & 3) + 8 * (r >> 2) + 4 * hl;
+                            stg[ch * 32 + nl] = __builtin_amdgcn_ldexpf(blk[r], un) + bias_g[m * 32 + ch];
                         }
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+                        for (int j = 0; j < 4; ++j) {
+                            const int co = m * 32 + (lane >> 3) + 8 * j;
+                            float4 v = *reinterpret_cast<const float4 *>(stg + ((lane >> 3) + 8 * j) * 32 + 4 * (lane & 7));
+                            if (y < a.H && x4 < a.W && (full || co < cout_g)) {
+                                const unsigned int o = (unsigned int)co * uplane + (unsigned int)(y * a.W + x4);
+                                float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+                                if (res) rr = *reinterpret_cast<const float4 *>(res + o);
+                                if (a.res_pre) { v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+                                if (a.act) {
+                                    v.x = split_act<GEN>(v.x, a.act); v.y = split_act<GEN>(v.y, a.act);
+                                    v.z = split_act<GEN>(v.z, a.act); v.w = split_act<GEN>(v.w, a.act);
+                                }
+                                if (!a.res_pre) { v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+                                if (a.post_op) {
+                                    const size_t po = (size_t)n * a.out_bstride + (size_t)grp * COUTP * plane + o;
+                                    const float4 q1 = *reinterpret_cast<const float4 *>(a.p1 + po);
+                                    if (a.post_op == 1) {
+                                        v.x *= q1.x; v.y *= q1.y; v.z *= q1.z; v.w *= q1.w;
+                                    } else {
+                                        const float4 q2 = *reinterpret_cast<const float4 *>(a.p2 + po);
+                                        v.x = (1.0f - q1.x) * q2.x + q1.x * v.x; v.y = (1.0f - q1.y) * q2.y + q1.y * v.y;
+                                        v.z = (1.0f - q1.z) * q2.z + q1.z * v.z; v.w = (1.0f - q1.w) * q2.w + q1.w * v.w;
+                                    }
+                                }
+                                if (a.clamp) {
+                                    v.x = fminf(fmaxf(v.x, 0.f), 1.f); v.y = fminf(fmaxf(v.y, 0.f), 1.f);
+                                    v.z = fminf(fmaxf(v.z, 0.f), 1.f); v.w = fminf(fmaxf(v.w, 0.f), 1.f);
+                                }
+                                *reinterpret_cast<float4 *>(out + o) = v;
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
                     }
                 }
             } else if (a.rows_channels > 0) {
