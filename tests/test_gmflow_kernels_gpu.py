@@ -425,3 +425,25 @@ def test_linear_layernorm128(hip, t, res, bias):
     lin = F.linear(xs.double(), w.double().cpu())
     ref = F.layer_norm(lin, (128,), g.double(), be.double())
     close(hip.linear_layernorm128(xs.cuda(), w, None, g.cuda(), be.cuda()), ref, "tokens of any magnitude", atol=3e-5, rtol=3e-5)
+
+
+@pytest.mark.parametrize("l", [1, 7, 28, 33, 65])
+def test_attention_tiny_sequences(hip, l):
+    """fewer keys than one 32-key tile, one more than a tile, ...: ragged first / last tiles of the streaming kernels"""
+    b = 3
+    q, k, v, v2 = rnd(b, l, 128), rnd(b, l, 128), rnd(b, l, 128), rnd(b, l, 2)
+    p = torch.softmax(torch.matmul(q.double(), k.double().transpose(1, 2)) / 128 ** 0.5, dim=-1)
+    close(hip.attention_tokens(q.cuda(), k.cuda(), v.cuda(), None, nsplit=1), torch.matmul(p, v.double()), "cv 128", atol=5e-5, rtol=1e-4)
+    close(hip.attention_tokens(q.cuda(), k.cuda(), v2.cuda(), None, nsplit=1), torch.matmul(p, v2.double()), "cv 2", atol=5e-5, rtol=1e-4)
+    q6, k6 = rnd(b, l, 64), rnd(b, l, 64)
+    v96 = torch.zeros(b, l, 96)
+    v96[:, :, :67] = rnd(b, l, 67)
+    p6 = torch.softmax(torch.matmul(q6.double(), k6.double().transpose(1, 2)) / 64, dim=-1)
+    lib = hip.lib()
+    out, stats, colsum = torch.empty(b, l, 96, device="cuda"), torch.empty(b, l, 2, device="cuda"), torch.empty(b, l, device="cuda")
+    qc, kc, vc = q6.cuda(), k6.cuda(), v96.cuda()
+    hip.check(lib.ct_attention_rows64_f32(qc.data_ptr(), kc.data_ptr(), vc.data_ptr(), out.data_ptr(), None, b, l, 1.0 / 64, None))
+    close(out[:, :, :67], torch.matmul(p6, v96.double())[:, :, :67], "rows64", atol=5e-5, rtol=1e-4)
+    hip.check(lib.ct_attention_rows64_f32(qc.data_ptr(), kc.data_ptr(), None, None, stats.data_ptr(), b, l, 1.0 / 64, None))
+    hip.check(lib.ct_attention_colsum64_f32(qc.data_ptr(), kc.data_ptr(), stats.data_ptr(), colsum.data_ptr(), b, l, 1.0 / 64, None))
+    close(colsum, p6.sum(dim=1), "column sums", atol=5e-5, rtol=1e-4)
