@@ -32,6 +32,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from stamp import read_stamped, source_stamp  # noqa: E402  (profiles/*.json are quoted only when measured on this tree's sources)
+
 H, W = 1080, 1920
 N_PIX = H * W
 PLANE_F32 = N_PIX * 3 * 4                    # 24 883 200 B
@@ -97,7 +100,6 @@ def video_stream(n_frames, dtype, device, rank, world, pool_size=16):
     main = torch.cuda.current_stream(device)
     depth = 3
     dev_raw = [torch.empty((3, H, W, 3), dtype=pool[0].dtype, device=device) for _ in range(depth)]
-    dev_f32 = torch.empty((3, H, W, 3), dtype=torch.float32, device=device)
     uploaded = [torch.cuda.Event() for _ in range(depth)]
     consumed = [torch.cuda.Event() for _ in range(depth)]
     out = torch.empty((1, H, W, 3), dtype=torch.float32, device=device)
@@ -114,12 +116,13 @@ def video_stream(n_frames, dtype, device, rank, world, pool_size=16):
     def process(i):
         slot = i % depth
         main.wait_event(uploaded[slot])
+        src = dev_raw[slot]
         if dtype == "u8":
-            torch.mul(dev_raw[slot], 1.0 / 255.0, out=dev_f32)   # uint8 -> float32 in [0, 1] (utils/data.py:84,106,125: .float() / 255)
-            src = dev_f32
+            # ct_reinhard_psnr_u8 reads the bytes: k / 255 (the reference's .float() / 255, utils/data.py:84,106,125) and its gamma
+            # expansion come out of 256-entry tables inside the kernel -- no conversion pass, no torch kernel in the loop
+            ct_hip.reinhard_persist(src[0:1], src[1:2], gt=src[2:3], out=out, psnr_out=rec[i:i + 1])
         else:
-            src = dev_raw[slot]
-        ct_hip.reinhard_psnr(src[0:1], src[1:2], src[2:3], out=out, psnr_out=rec[i:i + 1])
+            ct_hip.reinhard_psnr(src[0:1], src[1:2], src[2:3], out=out, psnr_out=rec[i:i + 1])
         consumed[slot].record(main)
 
     # initialisation: code objects, clocks, the communicator
@@ -150,6 +153,7 @@ def video_stream(n_frames, dtype, device, rank, world, pool_size=16):
     return {"frames": n_frames, "host_dtype": dtype, "frames_per_s": n_frames / dt, "ms_per_frame_per_gpu": dt / max(n_local, 1) * 1e3,
             "h2d_GB_per_s_per_gpu": bytes_per_frame * n_local / dt / 1e9, "h2d_bytes_per_frame": bytes_per_frame,
             "pcie_gen5_x16_GB_per_s": 63.0, "mean_psnr": float(table[:, 0].mean()),
+            "entry": "ct_reinhard_psnr_u8 (persistent launch, reads the bytes)" if dtype == "u8" else "ct_reinhard_psnr_f32",
             "note": "uploads (3 frames per stereo triple) on a copy stream two frames ahead, one pair per Reinhard call, PSNR fused, "
                     "one gather; host frames from a pool of %d pinned triples" % pool_size}
 
@@ -172,15 +176,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     from utils.sharding import pin_rank_to_cpus
     pin_rank_to_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))      # one CPU slice per rank, before any GPU call
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    ranks_seen = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        assert dist.get_world_size() == args.gpus, "--gpus %d but the communicator has %d ranks" % (args.gpus, dist.get_world_size())
+        one = torch.ones(1, dtype=torch.int64, device=device)
+        dist.all_reduce(one)                            # counted by the communicator itself, not read from the environment
+        ranks_seen = int(one.item())
+        assert ranks_seen == args.gpus
 
     import ct_hip
     import methods.linear as lin
@@ -226,9 +235,11 @@ def main():
         dist.all_gather_into_tensor(gathered, metrics)      # warms the communicator
     barrier()
     t_init = time.perf_counter()
+    init_steps = 1
     while time.perf_counter() - t_init < args.init_seconds:
         for _ in range(8):
             step(0)
+        init_steps += 8
         torch.cuda.synchronize()
     for i in range(Wm):
         step(i % K)
@@ -298,15 +309,14 @@ def main():
         # HBM traffic per launch of the dominant kernel from the committed PMC profile (separate --pmc passes,
         # FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md "HBM"), valid for the same pairs-per-step only
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if tj.get("pairs_per_step") == B and tj.get("lab_mode") == ct_hip.lab_mode():
-                traffic = tj.get("hbm_bytes_per_launch", {}).get(dom)
+        tj = read_stamped(os.path.join(ROOT, "profiles", "r04_traffic.json"))     # None unless measured on THIS tree's kernel sources
+        if tj and tj.get("pairs_per_step") == B and tj.get("lab_mode") == ct_hip.lab_mode():
+            traffic = tj.get("hbm_bytes_per_launch", {}).get(dom)
         t_kernels = t_stats + t_apply
         roof = {"bound": "hbm", "kernel": dom, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": ach / HBM_PEAK, "traffic": traffic,
-                "traffic_source": "profiles/r03_traffic.json (rocprofv3 --pmc passes of this command; not live)" if traffic else None,
+                "traffic_source": ("profiles/r04_traffic.json (rocprofv3 --pmc passes of this command on a build with source stamp %s; not live)" % source_stamp()) if traffic
+                else "no PMC profile of this build under profiles/ (stamp %s)" % source_stamp(),
                 "algorithmic_bytes_per_launch": kern[dom]["bytes"],
                 "algorithmic_bytes_note": "2 float32 planes x %d pairs (SURVEY 8d): %s" % (
                     B, "target read + result write" if dom == k_apply else "target + reference read"),
@@ -339,7 +349,29 @@ def main():
                     fn()
                 torch.cuda.synchronize()
                 return n / (time.perf_counter() - t0)
+
+            def forward_ms(fn, n=10, warm=3):
+                """one whole forward per sample, HIP events on the launch stream: median and min of n after `warm` warm-ups"""
+                for _ in range(warm):
+                    fn()
+                ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+                for a, b in ev:
+                    a.record()
+                    fn()
+                    b.record()
+                torch.cuda.synchronize()
+                ms = sorted(a.elapsed_time(b) for a, b in ev)
+                return {"median_ms": float(np.median(ms)), "min_ms": ms[0], "n": n, "warmup": warm, "timer": "HIP events"}
             extra["reinhard_pairs_per_s_transfer_only"] = B * rate(lambda: ct_hip.reinhard(tgt, ref, out=out), n=200)
+            # the one-launch form (csrc/reinhard_persist.hip): float32 frames by name, uint8 frames through the u8 front door
+            pr = torch.zeros((B, 2), dtype=torch.float64, device=device)
+            extra["reinhard_persist_f32_pairs_per_s_with_psnr"] = B * rate(lambda: ct_hip.reinhard_persist(tgt, ref, gt=gt, out=out, psnr_out=pr), n=100)
+            t8, r8, g8 = ((x * 255).round().to(torch.uint8) for x in (tgt, ref, gt))
+            extra["reinhard_u8_pairs_per_s_with_psnr"] = B * rate(lambda: ct_hip.reinhard_persist(t8, r8, gt=g8, out=out, psnr_out=pr), n=100)
+            extra["reinhard_u8_pairs_per_s_transfer_only"] = B * rate(lambda: ct_hip.reinhard_persist(t8, r8, out=out), n=100)
+            extra["reinhard_u8_note"] = ("ct_reinhard_psnr_u8: uint8 frames (what the reference's datasets deliver, utils/data.py:84) read as bytes; "
+                                         "algorithmic bytes per pair 2 x 6.2 MB in + 24.9 MB out")
+            del t8, r8, g8, pr
             o_nchw, g_nchw = out.permute(0, 3, 1, 2).contiguous(), gt.permute(0, 3, 1, 2).contiguous()
             extra["frames_per_s_psnr"] = B * rate(lambda: ct_hip.frame_psnr(out, gt), n=100)
             extra["frames_per_s_ssim"] = B * rate(lambda: ct_hip.frame_ssim(o_nchw, g_nchw), n=100)
@@ -381,22 +413,24 @@ def main():
             torch.manual_seed(0)
             net = DCMCS3DI().to(device).eval()
             l512, r512 = torch.rand(1, 3, 512, 512, device=device), torch.rand(1, 3, 512, 512, device=device)
-            dc = rate(lambda: net(l512, r512, inference=True), n=5)
+            t512 = forward_ms(lambda: net(l512, r512, inference=True))
+            dc = 1e3 / t512["median_ms"]
+            extra["dcmcs3di_512_forward"] = t512
             flop = 512 * 512 * (6591040 + 390 * 512)
             extra["dcmcs3di_512_pairs_per_s_f32"] = dc
             extra["dcmcs3di_512_tflops"] = flop * dc / 1e12
             extra["dcmcs3di_512_frac_16bit_mfma_peak_issued"] = mfma_per_flop * flop * dc / 2.5e15   # MFMA flops issued per algorithmic flop
             # the size BASELINE.json's metric names: 1920x1080 (H*W*(6591040 + 390*W) FLOP/pair)
             l1080, r1080 = torch.rand(1, 3, H, W, device=device), torch.rand(1, 3, H, W, device=device)
-            dc2 = rate(lambda: net(l1080, r1080, inference=True), n=3)
+            t1080 = forward_ms(lambda: net(l1080, r1080, inference=True))
+            dc2 = 1e3 / t1080["median_ms"]
             flop2 = H * W * (6591040 + 390 * W)
             extra["dcmcs3di_1080p_pairs_per_s_f32"] = dc2
             # the second roofline object: the CNN half of BASELINE.json's metric.  bound = the bf16 matrix pipe (the one the
             # kernels run on: 6 bf16 MFMAs per float32 product in the convolutions and the q.k scores); `frac` = MFMA-busy from
             # the committed counter profile of the same forward (SQ_VALU_MFMA_BUSY_CYCLES over all kernels of the run, time
             # weighted, profiles/r02_dcmcs3di_1080p_mfma_pmc.json); achieved = issued bf16-MFMA-equivalent work, live.
-            pm = os.path.join(ROOT, "profiles", "r03_dcmcs3di_1080p_mfma_pmc.json")
-            busy = json.load(open(pm)) if os.path.exists(pm) else {}
+            busy = read_stamped(os.path.join(ROOT, "profiles", "r04_dcmcs3di_1080p_mfma_pmc.json")) or {}      # {} unless measured on this tree's sources
             kdom = [v for k, v in busy.items() if "conv_ws_kernel" in k]
             roof_cnn = {"bound": "mfma", "workload": "dcmcs3di forward, random init, 1 pair of 1920x1080, float32 I/O",
                         "dtype": "16-bit MFMA pipe (float32 operands as 2 fp16 pieces / 3 MFMAs per product in the convolutions and the "
@@ -404,7 +438,10 @@ def main():
                         "achieved": mfma_per_flop * flop2 * dc2 / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                         "frac_flops": mfma_per_flop * flop2 * dc2 / 2.5e15,
                         "frac": busy.get("_all_kernels", {}).get("mfma_busy_frac_time_weighted"),
-                        "frac_source": "profiles/r03_dcmcs3di_1080p_mfma_pmc.json (rocprofv3 --pmc pass of the same forward; not live)",
+                        "frac_source": ("profiles/r04_dcmcs3di_1080p_mfma_pmc.json: ONE rocprofv3 --pmc run of the same forward on a build with source "
+                                        "stamp %s (not live)" % source_stamp()) if busy else
+                                       "no PMC profile of this build under profiles/ (source stamp %s): frac is null, never a stale number" % source_stamp(),
+                        "forward": t1080,
                         "frac_definition": "MFMA-busy: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), time-weighted over every "
                                            "kernel of the forward",
                         "dominant_kernel": "conv_ws_kernel<1, true>",
@@ -419,14 +456,16 @@ def main():
             gm = GMFlow().to(device)
             a960, b960 = torch.rand(1, 3, 540, 960, device=device) * 255, torch.rand(1, 3, 540, 960, device=device) * 255
             size = DMSCT.derive_matcher_inference_size(a960.shape)
-            gr = rate(lambda: gm(a960, b960, inference_size=size, pred_bidir_flow=True, fwd_bwd_consistency_check=True), n=3)
+            tgm = forward_ms(lambda: gm(a960, b960, inference_size=size, pred_bidir_flow=True, fwd_bwd_consistency_check=True))
+            gr = 1e3 / tgm["median_ms"]
             extra["gmflow_960x540_pairs_per_s_f32"] = gr
+            extra["gmflow_960x540_forward"] = tgm
             # the reference's algorithmic FLOPs per pair; 0.376e12 of them (the SepConvGRU's loop-invariant input blocks)
             # are convolved once per forward instead of once per refinement iteration, so this is a throughput equivalent
             extra["gmflow_960x540_tflops_f32_equivalent"] = 3.58357106688e12 * gr / 1e12
-            pm = os.path.join(ROOT, "profiles", "r03_gmflow_960x540_mfma_pmc.json")
-            if os.path.exists(pm):
-                extra["gmflow_960x540_mfma_busy_time_weighted"] = json.load(open(pm)).get("_all_kernels", {}).get("mfma_busy_frac_time_weighted")
+            gmp = read_stamped(os.path.join(ROOT, "profiles", "r04_gmflow_960x540_mfma_pmc.json"))
+            extra["gmflow_960x540_mfma_busy_time_weighted"] = gmp.get("_all_kernels", {}).get("mfma_busy_frac_time_weighted") if gmp else None
+            if gmp:
                 extra["gmflow_960x540_mfma_busy_note"] = ("MFMA-busy is not comparable across arithmetic forms: the fp16 two-piece kernels issue "
                                                           "half the MFMA cycles per product of the bf16 three-piece ones they replaced "
                                                           "(33 -> 24 ms per pair at 0.245 -> 0.22 busy)")
@@ -434,7 +473,9 @@ def main():
             dm = DMSCT().to(device).eval()
             dm.matcher = gm
             t960, r960 = a960 / 255, b960 / 255
-            extra["dmsct_960x540_pairs_per_s_f32"] = rate(lambda: dm(t960, r960), n=3)
+            tdm = forward_ms(lambda: dm(t960, r960))
+            extra["dmsct_960x540_pairs_per_s_f32"] = 1e3 / tdm["median_ms"]
+            extra["dmsct_960x540_forward"] = tdm
             del dm
 
     # configs[4] with the uploads inside the measurement: every rank takes part (frame f -> rank f % world)
@@ -454,7 +495,9 @@ def main():
     if rank == 0:
         line = {
             "metric": BASELINE_METRIC,
-            "value": value, "unit": "stereopairs/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "value": value, "unit": "stereopairs/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": K, "warmup": Wm,
+            "init_seconds": args.init_seconds, "init_steps": init_steps,      # un-timed steps BEFORE the W warm-up steps (code objects, clocks)
+            "source_stamp": source_stamp(),
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE[ct_hip.lab_mode()], "data": "synthetic",
             # the other half of BASELINE.json's metric: dcmcs3di forward at 1920x1080 on the same GPU (details: roofline_cnn)

@@ -71,14 +71,15 @@ __global__ __launch_bounds__(512) void conv_smallcout_kernel(GConvArgs a, int ti
         if (K == 3) {
             float x[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) x[t] = ip[off[t]] * msk[t];
+            for (int t = 0; t < 9; ++t) { const float v = ip[off[t]]; x[t] = msk[t] != 0.f ? v : 0.f; }      // select, not multiply: inf / nan at (0,0) must not leak into the padding
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const float4 w4 = wp[t];
                 acc.x = fmaf(x[t], w4.x, acc.x); acc.y = fmaf(x[t], w4.y, acc.y); acc.z = fmaf(x[t], w4.z, acc.z); acc.w = fmaf(x[t], w4.w, acc.w);
             }
         } else {
-            const float x = ip[off[0]] * msk[0];
+            const float v = ip[off[0]];
+            const float x = msk[0] != 0.f ? v : 0.f;
             const float4 w4 = wp[0];
             acc.x = fmaf(x, w4.x, acc.x); acc.y = fmaf(x, w4.y, acc.y); acc.z = fmaf(x, w4.z, acc.z); acc.w = fmaf(x, w4.w, acc.w);
         }

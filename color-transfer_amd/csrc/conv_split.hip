@@ -652,7 +652,7 @@ int conv_split(const ConvArgs &a, int N, int kh, int kw, bool gen, hipStream_t s
                      ((reinterpret_cast<uintptr_t>(a.wp) & 15) == 0) &&
                      (!a.residual || (((reinterpret_cast<uintptr_t>(a.residual) & 15) == 0) && (a.res_bstride % 4 == 0)));
     if (!vec) return 1;
-    if (a.rows_channels > 0 && ((a.rows_channels & 3) || (a.rows_c0 & 3) || a.rows_c0 + a.cout > a.rows_channels || a.residual || a.clamp))
+    if (a.rows_channels > 0 && ((a.rows_channels & 3) || (a.rows_c0 & 3) || (a.cout & 3) || a.rows_c0 + a.cout > a.rows_channels || a.residual || a.clamp))
         return CT_E_BADARG;
     if (kh == 3 && kw == 3 && a.rows_channels == 0 && !a.res_pre && !a.post_op) {
         const int rc = conv_ws(a, N, gen, s);

@@ -446,6 +446,7 @@ int conv_ws(const ConvArgs &a, int N, bool gen, hipStream_t s) {
     if (a.prof != nullptr) return 1;
 #endif
     if ((!enabled && !a.f16) || a.in2 != nullptr || a.cin <= 32 || a.cin > 64) return 1;
+    if ((unsigned long long)a.H * (unsigned long long)a.W * 64ull >= (1ull << 32)) return 1;     // the kernel indexes a 64-channel image with 32 bits: the tile kernel takes larger ones
     const int n_strips = (a.W + kWsTW - 1) / kWsTW;
     // row segments: the split that minimises the row steps of the busiest workgroup (32 workgroups per XCD sweep the bands
     // of that XCD; a segment costs its rows + 2 halo rows of staging)

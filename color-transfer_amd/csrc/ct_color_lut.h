@@ -104,8 +104,12 @@ constexpr int32_t kToeHiInv = 0x3fca7b96;    // high word of 0.2068966
 // one pixel (float32, all three in [0,1]) -> (fx, fy, fz).  The linear toe of Lab's f() is patched behind ONE integer
 // test on the high words (positive doubles order like their bit patterns): the float64 selects run only when some
 // lane of the wave needs them.
+__device__ __forceinline__ void lin_to_f(const unsigned char *lds, double lr, double lg, double lb, double &fx, double &fy, double &fz);
 __device__ __forceinline__ void rgb_to_f(const unsigned char *lds, float r, float g, float b, double &fx, double &fy, double &fz) {
-    const double lr = expand(lds, r), lg = expand(lds, g), lb = expand(lds, b);
+    lin_to_f(lds, expand(lds, r), expand(lds, g), expand(lds, b), fx, fy, fz);
+}
+// the same from linear (gamma-expanded) values: uint8 frames look their 256 possible expansions up (reinhard_persist.hip)
+__device__ __forceinline__ void lin_to_f(const unsigned char *lds, double lr, double lg, double lb, double &fx, double &fy, double &fz) {
     const double x = fma(lb, CT_M02, fma(lg, CT_M01, lr * CT_M00));
     const double y = fma(lb, CT_M12, fma(lg, CT_M11, lr * CT_M10));
     const double z = fma(lb, CT_M22, fma(lg, CT_M21, lr * CT_M20));
@@ -198,6 +202,44 @@ __device__ __forceinline__ void rgb_to_f32(const unsigned char *lds, float r, fl
     fx = cbrt32(lds, x);
     fy = cbrt32(lds, y);
     fz = cbrt32(lds, z);
+    if (__builtin_amdgcn_ballot_w64(fminf(fminf(x, y), z) <= 0.008856f)) {
+        asm volatile("; lab toe" : "+v"(fx));
+        fx = (x > 0.008856f) ? fx : fmaf(7.787f, x, (float)(16.0 / 116.0));
+        fy = (y > 0.008856f) ? fy : fmaf(7.787f, y, (float)(16.0 / 116.0));
+        fz = (z > 0.008856f) ? fz : fmaf(7.787f, z, (float)(16.0 / 116.0));
+    }
+}
+
+// ---- float32 pieces on the float64-grade tables (reinhard_persist.hip: its LDS has no room for A32 / B32) -----------------------
+// gamma expansion from table A: a0 rounded to float32 (to nearest: the error differs from node to node, no common bias), the
+// node distance from the index exactly as expand() forms it
+__device__ __forceinline__ float expand32_a(const unsigned char *lds, float c) {
+    const float y = fmaf(c, kAScale, kMagic);
+    const uint32_t off = (__float_as_uint(y) << 4) - (kMagicBits << 4);
+    const float d = fmaf(y - kMagic, kANegInv, c);
+    const uint4 e = *reinterpret_cast<const uint4 *>(lds + kLdsA + CT_LUT_OFF(off, 16));
+    const float a0 = (float)__hiloint2double((int)e.y, (int)e.x);
+    return fmaf(d, fmaf(d, __uint_as_float(e.w), __uint_as_float(e.z)), a0);
+}
+// cube root without a table: r ~ v^(-1/3) from the hardware log2 / exp2 (~5e-7 relative), u = v r^2, one correction step in the
+// residual u r = v r^3 (exact out of one fma): < 8e-8 relative, symmetric (measured round 3: as fast as the B32 look-up)
+__device__ __forceinline__ float cbrt32_hw(float v) {
+    const float r = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(v) * (-1.0f / 3.0f));
+    const float u = (v * r) * r;
+    const float e = fmaf(-u, r, 1.0f);
+    return fmaf(u * (2.0f / 3.0f), e, u);
+}
+__device__ __forceinline__ void lin32_to_f32(float lr, float lg, float lb, float &fx, float &fy, float &fz);
+__device__ __forceinline__ void rgb_to_f32_a(const unsigned char *lds, float r, float g, float b, float &fx, float &fy, float &fz) {
+    lin32_to_f32(expand32_a(lds, r), expand32_a(lds, g), expand32_a(lds, b), fx, fy, fz);
+}
+__device__ __forceinline__ void lin32_to_f32(float lr, float lg, float lb, float &fx, float &fy, float &fz) {
+    const float x = CT_ROW32(lr, lg, lb, CT_M00, CT_M01, CT_M02);
+    const float y = CT_ROW32(lr, lg, lb, CT_M10, CT_M11, CT_M12);
+    const float z = CT_ROW32(lr, lg, lb, CT_M20, CT_M21, CT_M22);
+    fx = cbrt32_hw(x);
+    fy = cbrt32_hw(y);
+    fz = cbrt32_hw(z);
     if (__builtin_amdgcn_ballot_w64(fminf(fminf(x, y), z) <= 0.008856f)) {
         asm volatile("; lab toe" : "+v"(fx));
         fx = (x > 0.008856f) ? fx : fmaf(7.787f, x, (float)(16.0 / 116.0));

@@ -14,9 +14,10 @@
 // Moments use the shifted-data form with a common pivot K = value of pixel 0 of the image:
 // S1 = sum(x-K), S2 = sum((x-K)(x-K)^T) are plainly additive across lanes/workgroups, and
 // mean = K + S1/n, M2 = S2 - S1 S1^T / n is stable in float64 even for near-constant images.
-#include "ct_color.h"
-#include "ct_color_lut.h"
-#include "ct_common.h"
+#include <atomic>
+
+#include "ct_reinhard.h"
+#include "ct_reinhard_persist.h"
 
 namespace ct {
 
@@ -45,31 +46,6 @@ static WsLayout ws_carve(void *ws, int n_images) {
 // -------------------------------------------------------------------------------------------
 // A1 / A3: first and second moments of Lab (LAB=true, 6 sums) or RGB (LAB=false, 9 sums)
 // -------------------------------------------------------------------------------------------
-template <bool LAB>
-__device__ __forceinline__ void to_space(double r, double g, double b, double &x, double &y, double &z) {
-    if (LAB) {
-        // moments are taken of (fy, fx - fy, fy - fz); L = 116 fy - 16, a = 500 (fx - fy),
-        // b = 200 (fy - fz) are per-axis affine images of those, applied once in the finishing kernel
-        double fx, fy, fz;
-        rgb_to_f(r, g, b, fx, fy, fz);
-        x = fy; y = fx - fy; z = fy - fz;
-    } else {
-        x = r; y = g; z = b;
-    }
-}
-
-template <bool LAB>
-__device__ __forceinline__ void accumulate(double (&s)[LAB ? 6 : 9], const double (&k)[3], double x, double y,
-                                           double z) {
-    const double dx = x - k[0], dy = y - k[1], dz = z - k[2];
-    s[0] += dx; s[1] += dy; s[2] += dz;
-    if (LAB) {
-        s[3] = fma(dx, dx, s[3]); s[4] = fma(dy, dy, s[4]); s[5] = fma(dz, dz, s[5]);
-    } else {
-        s[3] = fma(dx, dx, s[3]); s[4] = fma(dx, dy, s[4]); s[5] = fma(dx, dz, s[5]);
-        s[6] = fma(dy, dy, s[6]); s[7] = fma(dy, dz, s[7]); s[8] = fma(dz, dz, s[8]);
-    }
-}
 
 // grid = (G, n_images). Images [0, n_first) live at base0, the rest at base1 (so that the
 // targets and references of a batch of pairs are swept by ONE launch).
@@ -135,18 +111,6 @@ __global__ __launch_bounds__(kBlock) CT_WPE void moments_kernel(const T *__restr
     }
 }
 
-// shifted sums of (fy, fx-fy, fy-fz) around pivot k over n pixels -> the Lab stats record {mean L,a,b ; std L,a,b ; n ; 0}
-__device__ __forceinline__ void lab_record(const double *s, const double *k, double n, double *o) {
-    const double m0 = s[0] / n, m1 = s[1] / n, m2 = s[2] / n;  // mean of (x - K)
-    // (fy, fx-fy, fy-fz) -> (L, a, b): scale 116/500/200, offset -16/0/0
-    o[0] = fma(116.0, k[0] + m0, -16.0); o[1] = 500.0 * (k[1] + m1); o[2] = 200.0 * (k[2] + m2);
-    // population variance (np.std, ddof 0); clamp the cancellation residue of constant images
-    const double v0 = fma(-s[0], m0, s[3]) / n, v1 = fma(-s[1], m1, s[4]) / n, v2 = fma(-s[2], m2, s[5]) / n;
-    o[3] = 116.0 * sqrt(v0 > 0.0 ? v0 : (v0 == v0 ? 0.0 : v0));
-    o[4] = 500.0 * sqrt(v1 > 0.0 ? v1 : (v1 == v1 ? 0.0 : v1));
-    o[5] = 200.0 * sqrt(v2 > 0.0 ? v2 : (v2 == v2 ? 0.0 : v2));
-    o[6] = n; o[7] = 0.0;
-}
 
 // grid = n_images, one workgroup each: adds the G partials in a fixed order and writes the record.
 template <bool LAB>
@@ -186,43 +150,6 @@ __global__ __launch_bounds__(kBlock) void moments_finalize_kernel(const double *
 }
 
 // -------------------------------------------------------------------------------------------
-// A2: Reinhard apply.  Lab is affine in (fx,fy,fz), so "to Lab, scale/shift, back from Lab"
-// collapses into one affine map in the cube-root domain:
-//   fy' = sL fy + cy ;  fx' = fy' + sa (fx - fy) + ca ;  fz' = fy' - sb (fy - fz) - cb
-// -------------------------------------------------------------------------------------------
-struct ReinhardCoef {
-    double sL, sa, sb, cy, ca, cb;
-};
-
-__device__ __forceinline__ ReinhardCoef reinhard_coef(const double *st, const double *sr) {
-    ReinhardCoef c;
-    c.sL = sr[3] / st[3];  // sigma_r / sigma_t   (inf/nan on a constant target, like the reference)
-    c.sa = sr[4] / st[4];
-    c.sb = sr[5] / st[5];
-    c.cy = (fma(-16.0 - st[0], c.sL, sr[0]) + 16.0) * (1.0 / 116.0);
-    c.ca = fma(-st[1], c.sa, sr[1]) * (1.0 / 500.0);
-    c.cb = fma(-st[2], c.sb, sr[2]) * (1.0 / 200.0);
-    return c;
-}
-
-template <typename T, bool OUT_LAB>
-__device__ __forceinline__ void reinhard_pixel(const ReinhardCoef &c, double r, double g, double b, T &o0, T &o1,
-                                               T &o2) {
-    double fx, fy, fz;
-    rgb_to_f(r, g, b, fx, fy, fz);
-    const double gy = fma(c.sL, fy, c.cy);
-    const double gx = gy + fma(c.sa, fx - fy, c.ca);
-    const double gz = gy - fma(c.sb, fy - fz, c.cb);
-    if (OUT_LAB) {
-        double L, A, B;
-        f_to_lab(gx, gy, gz, L, A, B);
-        o0 = (T)L; o1 = (T)A; o2 = (T)B;
-    } else {
-        double R, G, Bc;
-        f_to_rgb(gx, gy, gz, R, G, Bc);
-        o0 = clip01<T>(R); o1 = clip01<T>(G); o2 = clip01<T>(Bc);
-    }
-}
 
 template <typename T, bool OUT_LAB>
 __global__ __launch_bounds__(kBlock) CT_WPE void reinhard_apply_kernel(const T *__restrict__ target,
@@ -272,9 +199,6 @@ __global__ __launch_bounds__(kBlock) CT_WPE void reinhard_apply_kernel(const T *
 // persistent: one round of resident workgroups sweeps all tiles.  A tile whose wave holds any value outside [0,1] (or a
 // NaN) is computed with the exact float64 code of ct_color.h, pixel by pixel.
 // -------------------------------------------------------------------------------------------
-constexpr int kLutBlock = 512;
-constexpr int kLutWaves = kLutBlock / kWave;
-constexpr int kTilePixels = 4 * kWave;
 // minimum waves per SIMD the table kernels are compiled for (register budget): tuning builds override
 #ifndef CT_LUT_WPE_STATS
 #define CT_LUT_WPE_STATS 4
@@ -286,63 +210,6 @@ constexpr int kTilePixels = 4 * kWave;
 #define CT_LUT_PREFETCH 1
 #endif
 
-typedef float float3v __attribute__((ext_vector_type(3)));
-typedef float3v float3u __attribute__((aligned(4)));
-
-__device__ __forceinline__ void load_tile(const float *tile, int lane, float (&e)[12]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float3v a = *reinterpret_cast<const float3u *>(tile + (j * kWave + lane) * 3);
-        e[3 * j] = a.x; e[3 * j + 1] = a.y; e[3 * j + 2] = a.z;
-    }
-}
-__device__ __forceinline__ void store_tile(float *tile, int lane, const float (&e)[12]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<float3u *>(tile + (j * kWave + lane) * 3) = float3v{e[3 * j], e[3 * j + 1], e[3 * j + 2]};
-}
-
-__device__ __forceinline__ uint32_t max_bits12(const float (&e)[12]) {
-    uint32_t m = 0;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) m = max(m, __float_as_uint(e[i]));
-    return m;
-}
-
-// rotate the four pixels of a lane by one: the exact fallback stays a rolled loop over "pixel 0" (one copy of the code,
-// few registers) without indexing the register array dynamically; four rotations restore the order
-__device__ __forceinline__ void rotate_pixels(float (&e)[12]) {
-    const float a = e[0], b = e[1], c = e[2];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) e[i] = e[i + 3];
-    e[9] = a; e[10] = b; e[11] = c;
-}
-__device__ __forceinline__ double uniform_f64(double v) {     // wave-uniform double -> SGPR pair
-    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
-}
-
-template <int NV, int NW>
-__device__ __forceinline__ void block_sum_n(double (&v)[NV], double *lds /* [NW][NV] */) {
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] += __shfl_down(v[i], off, kWave);
-    }
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wid = threadIdx.x >> 6;
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) lds[wid * NV + i] = v[i];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            double a = lds[i];
-            for (int w = 1; w < NW; ++w) a += lds[w * NV + i];   // wave order: fixed
-            v[i] = a;
-        }
-    }
-}
 
 // A1, float32 arithmetic on the table path (see ct_color_lut.h: statistics only need unbiased per-pixel values): per lane
 // float32 shifted sums over its ~40 pixels, converted once to float64 for the fixed-shape reduction tree.  The exact
@@ -859,11 +726,15 @@ static int check_ws(const void *ws, size_t ws_bytes, int n_images) {
 
 // Optional HIP events bracketing the two streaming kernels of the Reinhard path (bench.py's roofline measurement):
 // set with ct_profile_events(); NULL = off.  Recorded on the launch stream, so they time exactly one kernel.
-static hipEvent_t g_prof_evt[4] = {nullptr, nullptr, nullptr, nullptr};
+static thread_local hipEvent_t g_prof_evt[4] = {nullptr, nullptr, nullptr, nullptr};     // per calling thread: the thread that set them launches the kernels they bracket
 
 // Lab arithmetic of the float32 entries: 0 = table-driven (ct_color_lut.h, default), 1 = exact float64 (ct_color.h).
-// float64 images always take the exact path.  Process-wide; set before launching (ct_set_lab_mode / env CT_HIP_LAB).
-static int g_lab_mode = [] { const char *e = getenv("CT_HIP_LAB"); return (e && e[0] == 'e') ? 1 : 0; }();
+// float64 images always take the exact path.  Two levels: a process-wide default (ct_set_lab_mode / env CT_HIP_LAB; atomic) and a
+// per-thread override (ct_set_lab_mode_thread; -1 = none), so that two host threads driving different streams with different
+// modes do not race on one global -- every entry reads the mode once, through lab_mode(), on the calling thread.
+static std::atomic<int> g_lab_mode_default{[] { const char *e = getenv("CT_HIP_LAB"); return (e && e[0] == 'e') ? 1 : 0; }()};
+static thread_local int t_lab_mode = -1;
+static inline int lab_mode() { return t_lab_mode >= 0 ? t_lab_mode : g_lab_mode_default.load(std::memory_order_relaxed); }
 
 // Workgroups of a table kernel: ONE round of persistent workgroups -- as many as are resident at once (occupancy query,
 // cached per kernel), each sweeping enough chunks to amortise its 32-37 KB table copy.  CT_HIP_LUT_BLOCKS overrides the
@@ -895,7 +766,7 @@ static int launch_moments(const T *base0, const T *base1, int n_first, int n_ima
     // number of partial sums per image, or stays 0 when this launch took a path that finishes here
     if (n_images == 0) return CT_OK;
     constexpr bool kLut = LAB && sizeof(T) == 4;
-    const bool use_lut = kLut && g_lab_mode == 0;
+    const bool use_lut = kLut && lab_mode() == 0;
     int G = blocks_per_image(n_pixels >> 2, n_images);
     if constexpr (kLut) {
         static const int resident = resident_blocks(lab_moments_lut_kernel);
@@ -929,7 +800,7 @@ static int launch_reinhard_apply(const T *target, const double *st, const double
                                  int *sq_blocks = nullptr) {
     if (batch == 0 || n_pixels == 0) return CT_OK;
     constexpr bool kLut = sizeof(T) == 4;
-    const bool use_lut = kLut && g_lab_mode == 0;
+    const bool use_lut = kLut && lab_mode() == 0;
     int G = blocks_per_image(n_pixels >> 2, batch);
     if constexpr (kLut) {
         static const int resident = resident_blocks(reinhard_apply_lut_kernel<OUT_LAB>);
@@ -982,6 +853,15 @@ static int reinhard_impl(const T *target, const T *reference, T *out, int64_t n_
     if ((rc = check_image_args(out, n_pixels, batch))) return rc;
     if ((rc = check_ws(ws, ws_bytes, 2 * batch))) return rc;
     if (batch == 0) return CT_OK;
+    if constexpr (sizeof(T) == 4) {
+        // frames whose 1 / CUs share fits one CU's LDS: one persistent launch (reinhard_persist.hip) instead of the two sweeps
+        if (lab_mode() == 0 && n_pixels > 0 && rp::eligible(n_pixels, false) && ws_bytes >= rp::ws_bytes(n_pixels, batch)) {
+            if (g_prof_evt[0]) (void)hipEventRecord(g_prof_evt[0], (hipStream_t)stream);
+            if (g_prof_evt[1]) (void)hipEventRecord(g_prof_evt[1], (hipStream_t)stream);
+            return rp::launch<float>(target, reference, nullptr, out, nullptr, n_pixels, batch, stats_out, ws, ws_bytes, (hipStream_t)stream,
+                                     g_prof_evt[2], g_prof_evt[3]);
+        }
+    }
     const WsLayout l = ws_carve(ws, 2 * batch);
     // one sweep over all 2*batch images; stats records [0,batch) = targets, [batch,2batch) = references
     double *stats = stats_out ? stats_out : l.stats;
@@ -1061,6 +941,11 @@ static int reinhard_psnr_impl(const float *target, const float *reference, const
     if (ws == nullptr || (reinterpret_cast<uintptr_t>(ws) & 15) || ws_bytes < ws_bytes_reinhard_psnr(batch)) return CT_E_WORKSPACE;
     if (batch == 0 || n_pixels == 0) return CT_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (lab_mode() == 0 && rp::eligible(n_pixels, false) && ws_bytes >= rp::ws_bytes(n_pixels, batch)) {
+        if (g_prof_evt[0]) (void)hipEventRecord(g_prof_evt[0], s);
+        if (g_prof_evt[1]) (void)hipEventRecord(g_prof_evt[1], s);
+        return rp::launch<float>(target, reference, gt, out, psnr_out, n_pixels, batch, stats_out, ws, ws_bytes, s, g_prof_evt[2], g_prof_evt[3]);
+    }
     const WsLayout l = ws_carve(ws, 2 * batch);
     double *sq = reinterpret_cast<double *>(reinterpret_cast<char *>(ws) + ws_bytes_for(2 * batch));
     double *stats = stats_out ? stats_out : l.stats;
@@ -1103,6 +988,21 @@ static int mk_impl(const T *target, const T *reference, TO *out, int64_t n_pixel
     return affine_impl<T, TO>(target, coef, out, n_pixels, batch, stream);
 }
 
+// the persistent launch by name (any frame size it supports; the automatic dispatch above only takes frames that fill every wave)
+template <typename T>
+static int reinhard_persist_entry(const T *target, const T *reference, const T *gt, float *out, double *psnr_out, int64_t n_pixels, int batch,
+                                  double *stats_out, void *ws, size_t ws_bytes, void *stream) {
+    int rc = check_image_args(target, n_pixels, batch);
+    if (rc) return rc;
+    if ((rc = check_image_args(reference, n_pixels, batch))) return rc;
+    if ((rc = check_image_args(out, n_pixels, batch))) return rc;
+    if (gt != nullptr && psnr_out == nullptr) return CT_E_BADARG;
+    if (batch == 0) return CT_OK;
+    if (!rp::eligible(n_pixels, true)) return CT_E_BADARG;
+    return rp::launch<T>(target, reference, gt, out, psnr_out, n_pixels, batch, stats_out, ws, ws_bytes, (hipStream_t)stream,
+                             g_prof_evt[2], g_prof_evt[3]);
+}
+
 }  // namespace ct
 
 // -------------------------------------------------------------------------------------------
@@ -1114,10 +1014,15 @@ int ct_abi_version(void) { return CT_ABI_VERSION; }
 
 int ct_set_lab_mode(int mode) {
     if (mode != CT_LAB_TABLE && mode != CT_LAB_EXACT) return CT_E_BADARG;
-    ct::g_lab_mode = mode;
+    ct::g_lab_mode_default.store(mode, std::memory_order_relaxed);
     return CT_OK;
 }
-int ct_get_lab_mode(void) { return ct::g_lab_mode; }
+int ct_get_lab_mode(void) { return ct::lab_mode(); }
+int ct_set_lab_mode_thread(int mode) {
+    if (mode != -1 && mode != CT_LAB_TABLE && mode != CT_LAB_EXACT) return CT_E_BADARG;
+    ct::t_lab_mode = mode;
+    return CT_OK;
+}
 
 void ct_profile_events(void *moments_start, void *moments_stop, void *apply_start, void *apply_stop) {
     ct::g_prof_evt[0] = (hipEvent_t)moments_start;
@@ -1137,13 +1042,13 @@ const char *ct_error_string(int code) {
 }
 
 size_t ct_workspace_bytes(int kind, int64_t n_pixels, int n_images) {
-    (void)n_pixels;
     if (n_images < 0) return 0;
     switch (kind) {
         case CT_WS_LAB_STATS:
         case CT_WS_RGB_MEANCOV: return ct::ws_bytes_for(n_images);
-        case CT_WS_REINHARD: return ct::ws_bytes_for(2 * n_images);
-        case CT_WS_REINHARD_PSNR: return ct::ws_bytes_reinhard_psnr(n_images);
+        case CT_WS_REINHARD: { const size_t a = ct::ws_bytes_for(2 * n_images), b = ct::rp::ws_bytes(n_pixels, n_images); return a > b ? a : b; }
+        case CT_WS_REINHARD_PSNR: { const size_t a = ct::ws_bytes_reinhard_psnr(n_images), b = ct::rp::ws_bytes(n_pixels, n_images); return a > b ? a : b; }
+        case CT_WS_REINHARD_PERSIST: return ct::rp::ws_bytes(n_pixels, n_images);
         default: return 0;
     }
 }
@@ -1195,6 +1100,17 @@ int ct_reinhard_f64(const double *target, const double *reference, double *out, 
 int ct_reinhard_psnr_f32(const float *target, const float *reference, const float *gt, float *out, double *psnr_out, int64_t n_pixels,
                          int batch, double *stats_out, void *ws, size_t ws_bytes, void *stream) {
     return ct::reinhard_psnr_impl(target, reference, gt, out, psnr_out, n_pixels, batch, stats_out, ws, ws_bytes, stream);
+}
+
+int ct_reinhard_persist_supported(int64_t n_pixels) { return ct::rp::eligible(n_pixels, true) ? 1 : 0; }
+int ct_reinhard_takes_persist(int64_t n_pixels) { return (ct::lab_mode() == 0 && ct::rp::eligible(n_pixels, false)) ? 1 : 0; }
+int ct_reinhard_persist_f32(const float *target, const float *reference, const float *gt, float *out, double *psnr_out, int64_t n_pixels,
+                            int batch, double *stats_out, void *ws, size_t ws_bytes, void *stream) {
+    return ct::reinhard_persist_entry<float>(target, reference, gt, out, psnr_out, n_pixels, batch, stats_out, ws, ws_bytes, stream);
+}
+int ct_reinhard_psnr_u8(const uint8_t *target, const uint8_t *reference, const uint8_t *gt, float *out, double *psnr_out, int64_t n_pixels,
+                        int batch, double *stats_out, void *ws, size_t ws_bytes, void *stream) {
+    return ct::reinhard_persist_entry<uint8_t>(target, reference, gt, out, psnr_out, n_pixels, batch, stats_out, ws, ws_bytes, stream);
 }
 
 int ct_rgb_meancov_f32(const float *rgb, int64_t n_pixels, int n_images, double *stats, void *ws, size_t ws_bytes,

@@ -18,10 +18,10 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CT_HIP_LIB") or os.path.join(_HERE, "libct_hip.so")   # CT_HIP_LIB: tuning builds only
 
-CT_ABI_VERSION = 4            # include/ct_hip.h: CT_ABI_VERSION; lib() refuses any other library
+CT_ABI_VERSION = 5            # include/ct_hip.h: CT_ABI_VERSION; lib() refuses any other library
 CT_LAB_STATS_STRIDE = 8
 CT_RGB_STATS_STRIDE = 16
-CT_WS_LAB_STATS, CT_WS_RGB_MEANCOV, CT_WS_REINHARD, CT_WS_IDT, CT_WS_REINHARD_PSNR = 0, 1, 2, 3, 4
+CT_WS_LAB_STATS, CT_WS_RGB_MEANCOV, CT_WS_REINHARD, CT_WS_IDT, CT_WS_REINHARD_PSNR, CT_WS_REINHARD_PERSIST = 0, 1, 2, 3, 4, 5
 
 _c_i64 = ctypes.c_int64
 _c_int = ctypes.c_int
@@ -35,6 +35,7 @@ SIGNATURES = {
     "ct_profile_events": (None, [_c_p, _c_p, _c_p, _c_p]),
     "ct_set_lab_mode": (_c_int, [_c_int]),
     "ct_get_lab_mode": (_c_int, []),
+    "ct_set_lab_mode_thread": (_c_int, [_c_int]),
     "ct_workspace_bytes": (_c_sz, [_c_int, _c_i64, _c_int]),
     "ct_lab_stats_f32": (_c_int, [_c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
     "ct_lab_stats_f64": (_c_int, [_c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
@@ -44,6 +45,10 @@ SIGNATURES = {
     "ct_reinhard_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
     "ct_reinhard_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
     "ct_reinhard_psnr_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
+    "ct_reinhard_persist_supported": (_c_int, [_c_i64]),
+    "ct_reinhard_takes_persist": (_c_int, [_c_i64]),
+    "ct_reinhard_persist_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
+    "ct_reinhard_psnr_u8": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
     "ct_rgb_meancov_f32": (_c_int, [_c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
     "ct_rgb_meancov_f64": (_c_int, [_c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
     "ct_mk_f32_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_int, _c_p, _c_sz, _c_p]),
@@ -199,13 +204,17 @@ def _suffix(t):
 CT_LAB_TABLE, CT_LAB_EXACT = 0, 1
 
 
-def set_lab_mode(mode):
+def set_lab_mode(mode, thread=False):
     """Lab arithmetic of the float32 Reinhard entries: "table" (default; LDS look-up tables, Lab within ~5e-7 of the
-    float64 path) or "exact" (float64 with hardware seeds).  Process-wide (ct_set_lab_mode, include/ct_hip.h)."""
+    float64 path) or "exact" (float64 with hardware seeds).  Process-wide default (ct_set_lab_mode), or -- thread=True -- an
+    override for the calling thread only (ct_set_lab_mode_thread; mode None removes it)."""
+    if thread and mode is None:
+        check(lib().ct_set_lab_mode_thread(-1))
+        return
     code = {"table": CT_LAB_TABLE, "exact": CT_LAB_EXACT}.get(mode)
     if code is None:
         raise ValueError("lab mode must be 'table' or 'exact', got %r" % (mode,))
-    check(lib().ct_set_lab_mode(code))
+    check(lib().ct_set_lab_mode_thread(code) if thread else lib().ct_set_lab_mode(code))
 
 
 def lab_mode():
@@ -305,6 +314,58 @@ def reinhard_psnr(target, reference, gt, out=None, psnr_out=None):
     check(lib().ct_reinhard_psnr_f32(_ptr(x), _ptr(r), _ptr(g), _ptr(out), _ptr(psnr_out), n, B, ctypes.c_void_p(0), _ptr(ws), ws.numel(),
                                      _stream()))
     return out.view(target.shape), psnr_out
+
+
+def reinhard_persist_supported(n_pixels):
+    """True when frames of n_pixels can take the one-launch Reinhard kernel on this device (csrc/reinhard_persist.hip)."""
+    return bool(lib().ct_reinhard_persist_supported(int(n_pixels)))
+
+
+def reinhard_takes_persist(n_pixels):
+    """True when reinhard() / reinhard_psnr() run float32 frames of n_pixels as the persistent launch (current Lab mode)."""
+    return bool(lib().ct_reinhard_takes_persist(int(n_pixels)))
+
+
+def reinhard_persist(target, reference, gt=None, out=None, psnr_out=None, stats_out=None, verify=False):
+    """color_transfer_between_images (methods/linear.py:8-42) for B pairs as ONE persistent launch, optionally with the
+    per-frame PSNR against `gt`.  float32 frames in [0,1] or uint8 frames (the reference's `.float() / 255`, utils/data.py:84);
+    the result is float32.  Returns out, or (out, psnr [B, 2]) with gt.  verify=True synchronises and raises if a workgroup of
+    the grid never became resident (results NaN)."""
+    x, _ = _as_batch(target)
+    r, _ = _as_batch(reference)
+    ts = [x, r]
+    g = None
+    if gt is not None:
+        g, _ = _as_batch(gt)
+        ts.append(g)
+    _require_cuda(*ts)
+    if any(t.shape != x.shape or t.dtype != x.dtype for t in ts) or x.dtype not in (torch.float32, torch.uint8):
+        raise CtHipError("reinhard_persist needs float32 or uint8 tensors of one shape")
+    B, n = x.shape[0], x.shape[1] * x.shape[2]
+    if not reinhard_persist_supported(n):
+        raise CtHipError("frames of %d pixels do not fit the persistent Reinhard launch on this device" % n)
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    if g is not None and psnr_out is None:
+        psnr_out = torch.empty((B, 2), dtype=torch.float64, device=x.device)
+    if stats_out is not None:
+        _require_cuda(stats_out)
+        if stats_out.dtype != torch.float64 or stats_out.numel() < 2 * B * CT_LAB_STATS_STRIDE:
+            raise CtHipError("stats_out must be float64 with >= 2*B*8 elements")
+    ws = workspace(CT_WS_REINHARD_PERSIST, n, B, x.device)
+    null = ctypes.c_void_p(0)
+    if x.dtype == torch.uint8:
+        fn = lib().ct_reinhard_psnr_u8
+    else:
+        fn = lib().ct_reinhard_persist_f32
+    check(fn(_ptr(x), _ptr(r), _ptr(g) if g is not None else null, _ptr(out), _ptr(psnr_out) if g is not None else null, n, B,
+                          _ptr(stats_out) if stats_out is not None else null, _ptr(ws), ws.numel(), _stream()))
+    if verify:
+        torch.cuda.synchronize()
+        if int(ws[:4].view(torch.int32)[0].item()) != 0:
+            raise CtHipError("persistent Reinhard launch: a workgroup of the grid never became resident (results are NaN)")
+    o = out.view(tuple(target.shape))
+    return (o, psnr_out) if g is not None else o
 
 
 def mk(target, reference, decomposition="MK", out_dtype=torch.float64, out=None):

@@ -55,11 +55,21 @@ def main(argv=None):
     from utils import sharding as sh
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     sh.pin_rank_to_cpus(int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("LOCAL_WORLD_SIZE", world)))   # before any GPU call
-    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
-    torch.cuda.set_device(device)
+    # CT_CLI_DEVICE=cpu: the host logic (argv / YAML handling, sharding, the one gather, the printed means) on CPU tensors with
+    # the gloo backend -- for tests of a multi-rank run without GPUs.  It is no compute fallback: methods.* still need the
+    # HIP library and raise without it; only a model whose test_step works on CPU tensors (a test stub) runs this way.
+    on_cpu = os.environ.get("CT_CLI_DEVICE", "cuda") == "cpu"
+    device = torch.device("cpu") if on_cpu else torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    if not on_cpu:
+        torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if on_cpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if dist.get_world_size() != world:
+            raise SystemExit("WORLD_SIZE=%d but the process group has %d ranks" % (world, dist.get_world_size()))
     model = _instantiate(cfg["model"]).to(device).eval()
     if ckpt:
         # Lightning checkpoints carry hyper-parameters / optimizer state next to "state_dict"; weights_only=True refuses the
@@ -91,7 +101,8 @@ def main(argv=None):
             batch = {k: v.unsqueeze(0) for k, v in sample.items()}
             if hasattr(model, "test_step"):
                 m = model.test_step(batch, f)
-                rows.append(torch.stack([m[k].reshape(()) for k in METRICS]))
+                nan = torch.full((), float("nan"), device=device)
+                rows.append(torch.stack([m[k].reshape(()).to(device) if k in m else nan for k in METRICS]))
             else:                                   # CNN modules: forward(target, reference, inference=True)
                 corrected, _ = model(batch["target"], batch["reference"], inference=True)
                 corrected = corrected.clamp(0, 1)

@@ -158,6 +158,10 @@ def prefetch(dataset, indices, device):
     indices = list(indices)
     if not indices:
         return
+    if torch.device(device).type == "cpu":          # utils.cli's CT_CLI_DEVICE=cpu test mode: host float datasets as they are
+        for index in indices:
+            yield index, dataset[index]
+        return
     copy_stream = torch.cuda.Stream(device=device)
     staged = [None, None]
     pinned = [{}, {}]

@@ -33,9 +33,10 @@ extern "C" {
 #define CT_E_WORKSPACE (-2)  /* workspace too small / misaligned */
 #define CT_E_ALIGN (-3)      /* image base not aligned to its element size */
 
-/* bumped whenever an entry point changes its argument list (2: ct_attention_tokens_f32 gained kv_shift; 3: round 3; 4: ct_conv2d_split_rows_f32, res_pre_act, ct_linear_ws16_f32, layernorm partials, f16 form of ct_conv2d_split*);
+/* bumped whenever an entry point changes its argument list (2: ct_attention_tokens_f32 gained kv_shift; 3: round 3; 4: ct_conv2d_split_rows_f32, res_pre_act, ct_linear_ws16_f32, layernorm partials, f16 form of ct_conv2d_split*;
+ * 5: ct_reinhard_persist_*, ct_reinhard_psnr_u8, CT_WS_REINHARD_PERSIST);
  * the ctypes binding refuses a library whose ct_abi_version() differs */
-#define CT_ABI_VERSION 4
+#define CT_ABI_VERSION 5
 
 /* doubles per image in a stats record written by ct_lab_stats / ct_rgb_meancov */
 #define CT_LAB_STATS_STRIDE 8  /* mean[3], std[3] (population, ddof 0), n, 0           */
@@ -46,7 +47,8 @@ enum ct_workspace_kind {
     CT_WS_RGB_MEANCOV = 1,
     CT_WS_REINHARD = 2,  /* ct_reinhard_*:  n_images = batch (pairs)                    */
     CT_WS_IDT = 3,       /* ct_idt_*:       n_images = batch (pairs)                    */
-    CT_WS_REINHARD_PSNR = 4 /* ct_reinhard_psnr_f32: n_images = batch (pairs)           */
+    CT_WS_REINHARD_PSNR = 4, /* ct_reinhard_psnr_f32: n_images = batch (pairs)          */
+    CT_WS_REINHARD_PERSIST = 5 /* ct_reinhard_persist_f32 / ct_reinhard_psnr_u8: n_images = batch (pairs); 0 = frame size not supported */
 };
 
 int ct_abi_version(void);
@@ -56,14 +58,19 @@ int ct_abi_version(void);
  *                           look-ups + short polynomials; Lab agrees with the float64 path to ~5e-7, statistics to ~1e-7;
  *                           values outside [0,1], NaNs and degenerate statistics fall back to the exact code per wave;
  *   CT_LAB_EXACT            float64 arithmetic with hardware seeds and one Newton correction (~1e-11 relative).
- * float64 images always take the exact path.  Process-wide setting, not thread safe; env CT_HIP_LAB=exact presets it. */
+ * float64 images always take the exact path.  ct_set_lab_mode: the process-wide default (atomic; env CT_HIP_LAB=exact presets
+ * it).  ct_set_lab_mode_thread: an override for the CALLING thread only (-1 = back to the default) -- host threads that drive
+ * different streams with different arithmetic each set their own; every entry reads the mode once, on the calling thread.
+ * ct_get_lab_mode: what the calling thread's next call will use.                                                          */
 #define CT_LAB_TABLE 0
 #define CT_LAB_EXACT 1
 int ct_set_lab_mode(int mode);
+int ct_set_lab_mode_thread(int mode);
 int ct_get_lab_mode(void);
 /* Measurement hook: four hipEvent_t (or NULL = off) that the library records on the launch stream immediately before /
  * after moments_kernel<T,true> and reinhard_apply_kernel of the following ct_lab_stats / ct_reinhard* calls, so that a
- * caller can time exactly those kernels with hipEventElapsedTime (bench.py `roofline`).  Not thread safe.              */
+ * caller can time exactly those kernels with hipEventElapsedTime (bench.py `roofline`).  When a call takes the persistent
+ * launch, the first pair is recorded back to back and the second pair brackets reinhard_persist_kernel.  Per calling thread. */
 void ct_profile_events(void *moments_start, void *moments_stop, void *apply_start, void *apply_stop);
 /* Human readable text for a return code of this library (never NULL). */
 const char *ct_error_string(int code);
@@ -106,6 +113,31 @@ int ct_reinhard_f64(const double *target, const double *reference, double *out,
  * not read back from HBM.  ws: ct_workspace_bytes(CT_WS_REINHARD_PSNR, n_pixels, batch).                               */
 int ct_reinhard_psnr_f32(const float *target, const float *reference, const float *gt, float *out, double *psnr_out,
                          int64_t n_pixels, int batch, double *stats_out, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- a1 as ONE persistent launch (csrc/reinhard_persist.hip): methods/linear.py:8-42 for `batch` pairs.  One workgroup per CU
+ * owns 1 / CUs of every frame; the cube-root-domain image of (up to 18 of) its target tiles waits in LDS for the statistics of
+ * the whole frame, which travel between the workgroups as 64-bit integer atomics one pair ahead of their use (the rest of its
+ * target tiles are fetched a second time); no launch boundary, no finishing kernels, one pass over the reference.
+ * Frame sizes: 256 pixels .. 16 Mpixel (ct_reinhard_persist_supported).  Measured at 1080p, 16 pairs per call: float32 frames
+ * 33 - 34 k pairs/s (the two sweeps of ct_reinhard_psnr_f32: 36.5 k -- both forms are bound by vector instruction issue and
+ * this one executes more instructions, so the fused float32 entries keep the two sweeps unless CT_HIP_REINHARD_PERSIST=1);
+ * uint8 frames 43 - 45 k pairs/s, which no other entry serves.
+ * gt = NULL: no metric (psnr_out unused); else psnr_out[i] = {mse, PSNR} like ct_reinhard_psnr_f32.
+ * ws: ct_workspace_bytes(CT_WS_REINHARD_PERSIST, n_pixels, batch).  After the call has completed, the first 32-bit word of
+ * ws is 0, or 1 when a workgroup of the grid never became resident within 2 s (results are then NaN).
+ * Bitwise reproducible run to run and independent of `batch`.                                                           */
+int ct_reinhard_persist_supported(int64_t n_pixels);
+/* 1 when ct_reinhard_f32 / ct_reinhard_psnr_f32 take the persistent launch for frames of this size in the current Lab mode */
+int ct_reinhard_takes_persist(int64_t n_pixels);
+int ct_reinhard_persist_f32(const float *target, const float *reference, const float *gt, float *out, double *psnr_out,
+                            int64_t n_pixels, int batch, double *stats_out, void *ws, size_t ws_bytes, void *stream);
+/* uint8 frames as the reference's datasets deliver them (utils/data.py:84,106,125: `read_image(...).float() / 255`): the
+ * kernel reads the bytes (a quarter of the float32 traffic) and takes k / 255 (IEEE float32 division) and its gamma
+ * expansion from 256-entry tables filled by the float32 kernel's own functions: per pixel the arithmetic is that of
+ * ct_reinhard_persist_f32 on `u8.float() / 255`; the frame statistics agree to their last float32 rounding (the moment terms
+ * are added in another lane order), results within 2e-7.  out: float32.                                               */
+int ct_reinhard_psnr_u8(const uint8_t *target, const uint8_t *reference, const uint8_t *gt, float *out, double *psnr_out,
+                        int64_t n_pixels, int batch, double *stats_out, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- A3: np.mean(axis=0) + np.cov(x.T)   (methods/linear.py:64-67,103-106) ----
  * stats[i*16 ..] = {mean[3] ; cov[9] row-major, ddof 1 ; n ; 0 0 0}.                     */
@@ -241,7 +273,8 @@ int ct_conv2d_f32(const float *in, const float *wp, const float *bias, const flo
  * transfer[0] reads cat([fea_left, fea_warped, valid_left]) (methods/dcmcs3di.py:59,47) from its three tensors.
  * f16 != 0: wp_split is the TWO-piece fp16 image of weight * 2^w_exp instead (ct_hip.pack_conv_weight_split16: same index order
  * with [piece hi,lo]; three v_mfma_f32_32x32x16_f16 per product, 2^-22 relative dropped; every staged 16-channel input tile
- * carries a running power-of-two scale per output tile, so any finite float32 input is in range) -- half the matrix work.
+ * carries a running power-of-two scale per output tile (exponent clamped to +-100), so inputs with |x| < 2^111 are in
+ * range; a tile maximum at or above 2^112 overflows fp16: inf / NaN results) -- half the matrix work.
  * post_op (f16 form only; p1 / p2 dense tensors with out's strides): 1 = the activated result times p1 (the GRU's r * h,
  * reg_refine.py:50), 2 = (1 - p1) * p2 + p1 * result (its gate h = (1 - z) h + z q, reg_refine.py:47,55), before the clamp.
  * residual: added after the activation (ResB skip), or -- res_pre_act != 0 -- BEFORE it: a pre-computed partial convolution
@@ -263,8 +296,9 @@ int ct_conv2d_split_rows_f32(const float *in, const void *wp_split, const float 
 /* The ResB convolutions (3x3, stride 1, padding 1, 32 < cin <= 64; reference pasmnet/backbone.py:8-15, unimatch/backbone.py
  * residual blocks) on the weight-stationary kernel of csrc/conv_ws.hip with float32 operands as TWO fp16 pieces and three
  * v_mfma_f32_32x32x16_f16 per 16-channel product (float32 accumulation; 2^-22 relative is dropped: float32-grade, not bitwise
- * the fmaf chain).  Every staged input row is scaled by a power of two of its own, the weights by 2^w_exp, so any finite
- * float32 input is in range.  wp16: fp16 bit patterns [ceil(cout/64)][ceil(cin/16)][9][piece hi/lo][m][k-half][cout%32][8]
+ * the fmaf chain).  Every staged input row is scaled by a power of two of its own (exponent clamped to +-100), the
+ * weights by 2^w_exp, so inputs with |x| < 2^111 are in range (a row maximum at or above 2^112 overflows fp16: inf / NaN
+ * results; the bf16 three-piece and exact-f32 modes have no such bound); 64 * h * w must be below 2^32 (32-bit indexing).  wp16: fp16 bit patterns [ceil(cout/64)][ceil(cin/16)][9][piece hi/lo][m][k-half][cout%32][8]
  * of weight * 2^w_exp; bias zero-padded to 64 * ceil(cout/64); act / clamp / residual as ct_conv2d_split_f32. */
 int ct_conv3x3_ws16_f32(const float *in, const void *wp16, int w_exp, const float *bias, const float *residual, float *out, int n,
                         int cin, int cout, int h, int w, long long in_bstride, long long out_bstride, long long res_bstride, int act,

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+_LIB_PATH = os.environ.get("CT_ORACLE_LIB") or os.path.join(_HERE, "_build", "liboracle.so")     # CT_ORACLE_LIB: the sanitizer build (make -C oracle asan)
 _lib = None
 
 

@@ -167,6 +167,8 @@ def test_conv_rows_argument_checks_and_fallback(hip):
     assert lib.ct_conv2d_split_rows_f32(p, p, p, p, 1, 64, 64, 8, 32, 1, 1, 64 * 8 * 32, 66, 0, 0, 0, 0, null) == -1
     assert lib.ct_conv2d_split_rows_f32(p, p, p, p, 1, 64, 64, 8, 32, 1, 1, 64 * 8 * 32, 64, 4, 0, 0, 0, null) == -1
     assert lib.ct_conv2d_split_rows_f32(p, p, p, p, 0, 64, 64, 8, 32, 1, 1, 64 * 8 * 32, 64, 0, 0, 0, 0, null) == 0
+    # cout % 4: the rows epilogue stores whole float4 groups -- a direct C-ABI caller must get CT_E_BADARG, not a write past channel cout
+    assert lib.ct_conv2d_split_rows_f32(p, p, p, p, 1, 64, 62, 8, 32, 1, 1, 64 * 8 * 32, 64, 0, 0, 0, 0, null) == -1
 
 
 def test_dcmcs3di_rows_path_equals_transposed_path(hip):

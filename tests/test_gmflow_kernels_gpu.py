@@ -51,6 +51,23 @@ def test_gconv(hip, cfg, conv_mode):
     close(hip.gconv2d(x.cuda(), wp, None, cout, (kh, kw), s, (ph, pw)), ref - b.double().view(1, -1, 1, 1), "no bias")
 
 
+@pytest.mark.parametrize("cfg", [(1, 16, 2, 12, 40, 3), (1, 8, 4, 9, 33, 1), (2, 32, 3, 20, 45, 3)])
+def test_small_cout_conv_zero_padding_is_a_select(hip, cfg):
+    """csrc/conv_direct.hip pads by clamping the tap address to pixel (0, 0): a non-finite value there must stay local (real zero
+    padding, the reference's F.conv2d, the MFMA kernels), not turn every border pixel into NaN through inf * 0"""
+    n, cin, cout, h, w, k = cfg
+    x, wt, b = rnd(n, cin, h, w), rnd(cout, cin, k, k) / (cin * k * k) ** 0.5, rnd(cout)
+    x[:, 0, 0, 0] = float("inf")
+    x[:, 1, 0, 0] = float("nan")
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=k // 2)
+    wp, bp = hip.pack_gconv_weight(wt.cuda(), b.cuda())
+    out = hip.gconv2d(x.cuda(), wp, bp, cout, (k, k), 1, (k // 2, k // 2)).cpu()
+    bad_ref = ~torch.isfinite(ref)
+    assert bad_ref.sum() <= n * cout * k * k                       # only the taps that really see pixel (0, 0)
+    assert torch.equal(~torch.isfinite(out), bad_ref)
+    close(out[~bad_ref], ref[~bad_ref], "small-cout conv beside a non-finite corner")
+
+
 @pytest.mark.parametrize("cfg", [
     (2, 64, 64, 24, 64, 3, 3), (1, 3, 64, 16, 32, 3, 3), (1, 64, 32, 9, 36, 3, 3), (1, 32, 3, 16, 40, 3, 3),
     (1, 129, 64, 8, 32, 1, 1), (2, 384, 128, 20, 68, 1, 5), (2, 384, 128, 21, 68, 5, 1), (1, 130, 256, 24, 64, 3, 3),

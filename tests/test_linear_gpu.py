@@ -356,3 +356,42 @@ def test_mk_device_algebra_vs_reference(golden_dir, lin, case):
     out = lin.monge_kantorovitch_color_transfer_cuda(dev(tb), dev(rb)).cpu().numpy()
     for b in range(3):
         np.testing.assert_allclose(out[b], olin.monge_kantorovitch_color_transfer(tb[b], rb[b]), rtol=0, atol=1e-9)
+
+
+def test_lab_mode_is_per_thread(hip):
+    """Two host threads, each with its own stream and its own Lab arithmetic (ct_set_lab_mode_thread), must not see each other's
+    mode: every call of a thread reproduces, bit for bit, what that mode gives single-threaded (include/ct_hip.h)."""
+    import threading
+    rng = np.random.default_rng(11)
+    x = dev(rng.random((300, 400, 3), dtype=np.float32))
+    want = {}
+    for m in ("table", "exact"):
+        hip.set_lab_mode(m)
+        want[m] = hip.lab_stats(x).clone()
+    hip.set_lab_mode("table")
+    assert not torch.equal(want["table"], want["exact"])          # the two arithmetics differ in the last digits
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(mode):
+        try:
+            hip.set_lab_mode(mode, thread=True)
+            assert hip.lab_mode() == mode
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(200):
+                    got = hip.lab_stats(x)
+                    if not torch.equal(got, want[mode]):
+                        errors.append((mode, (got - want[mode]).abs().max().item()))
+                        break
+                torch.cuda.current_stream().synchronize()
+            hip.set_lab_mode(None, thread=True)
+        except Exception as e:                                    # noqa: BLE001
+            errors.append((mode, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(m,)) for m in ("table", "exact", "exact", "table")]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    assert hip.lab_mode() == "table"                               # the process default was never touched

@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof_r04 (written on the GPU box by tools/gpu_profile_r04.sh) -> the tracked summaries under profiles/, each
+stamped with the source stamp of the build that was measured (tools/stamp.py; refused when it is not this tree's):
+kernel-stats CSVs, bench JSON lines, HBM traffic + instruction counts of the Reinhard kernels (r04_traffic.json), MFMA-busy
+summaries of the CNN forwards."""
+import csv, glob, json, os, shutil, subprocess, sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof_r04")
+DST = os.path.join(ROOT, "profiles")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from stamp import source_stamp
+STAMP = open(os.path.join(SRC, "source_stamp.txt")).read().strip()
+if STAMP != source_stamp():
+    sys.exit("gpurun_out/prof_r04 was measured on sources with stamp %s, this tree has %s: re-run tools/gpu_profile_r04.sh" % (STAMP, source_stamp()))
+try:
+    HEAD = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
+    DIRTY = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "color-transfer_amd/csrc", "include"], capture_output=True, text=True).stdout.strip())
+except OSError:
+    HEAD, DIRTY = None, None
+STAMPS = {"source_stamp": STAMP, "git_head_at_collection": HEAD, "kernel_sources_uncommitted_at_collection": DIRTY}
+
+
+def newest(sub, pattern):
+    """gpurun merges a call's files INTO the local gpurun_out/: an earlier call's outputs may still lie beside the new ones"""
+    f = glob.glob(os.path.join(SRC, sub, "**", pattern), recursive=True)
+    return max(f, key=os.path.getmtime) if f else None
+
+
+def stats_csv(sub, name):
+    f = newest(sub, "*kernel_stats.csv")
+    if f:
+        shutil.copy(f, os.path.join(DST, name))
+        print("wrote", name)
+
+
+def counters(sub):
+    agg = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    f = newest(sub, "*counter_collection.csv")
+    if f:
+        for row in csv.DictReader(open(f)):
+            a = agg[row["Kernel_Name"]][row["Counter_Name"]]
+            a[0] += float(row["Counter_Value"]); a[1] += 1
+    return {k: {c: v[0] / v[1] for c, v in d.items()} for k, d in agg.items()}
+
+
+stats_csv("trace", "r04_reinhard_bench_kernel_stats.csv")
+stats_csv("trace_dc1080", "r04_dcmcs3di_1080p_kernel_stats.csv")
+stats_csv("trace_gm960", "r04_gmflow_960x540_kernel_stats.csv")
+stats_csv("trace_dmsct960", "r04_dmsct_960x540_kernel_stats.csv")
+stats_csv("trace_idt", "r04_idt_kernel_stats.csv")
+for a, b in (("bench_under_rocprofv3.json", "r04_bench_under_rocprofv3.json"), ("bench_default.json", "r04_bench_default.json"),
+             ("bench_20_5.json", "r04_bench_20_5.json")):
+    p = os.path.join(SRC, a)
+    if os.path.exists(p) and os.path.getsize(p):
+        shutil.copy(p, os.path.join(DST, b)); print("wrote", b)
+
+# ---- Reinhard: HBM bytes (MI355X_MICROARCH.md: gfx950 FETCH_SIZE counts 64 B per 128-B request) + instruction counts
+bench = json.load(open(os.path.join(SRC, "bench_under_rocprofv3.json")))
+pairs = bench["config"]["pairs_per_step_per_gpu"]
+H, W = bench["config"]["height"], bench["config"]["width"]
+per = defaultdict(dict)
+for sub in sorted(os.listdir(SRC)):
+    if sub.startswith("pmc_") and os.path.isdir(os.path.join(SRC, sub)):
+        for k, d in counters(sub).items():
+            if "lab_moments_lut_kernel" in k or "reinhard_apply_lut_kernel" in k or "lab_moments_kernel" in k or "reinhard_apply_kernel" in k:
+                short = k.split("ct::")[-1].split("(")[0].replace("void ", "")
+                per[short].update(d)
+alg = 2 * 3 * 4 * H * W * pairs            # two float32 frames per pair, read or written once by each sweep
+out = {**STAMPS, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* in separate passes over `bench.py --steps 20 --warmup 5` "
+                 "(tools/gpu_profile_r04.sh, tools/collect_profiles_r04.py)",
+       "pairs_per_step": pairs, "lab_mode": bench["config"].get("lab_arithmetic"),
+       "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE x 1024 (MI355X_MICROARCH.md, HBM)",
+       "hbm_bytes_per_launch": {}, "algorithmic_bytes_per_launch": alg, "per_kernel": {}}
+for k, d in per.items():
+    e = dict(d)
+    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        e["FETCH_SIZE_KB"], e["WRITE_SIZE_KB"] = e.pop("FETCH_SIZE"), e.pop("WRITE_SIZE")
+        e["read_bytes"], e["write_bytes"] = int(2 * e["FETCH_SIZE_KB"] * 1024), int(e["WRITE_SIZE_KB"] * 1024)
+        out["hbm_bytes_per_launch"][k] = e["read_bytes"] + e["write_bytes"]
+        fused_psnr = "apply" in k and bench["config"].get("metrics") == ["psnr"] and out["lab_mode"] == "table"
+        e["algorithmic_bytes"] = alg * 3 // 2 if fused_psnr else alg      # + the ground-truth plane of the fused per-frame PSNR
+        e["traffic_over_algorithmic"] = (e["read_bytes"] + e["write_bytes"]) / e["algorithmic_bytes"]
+    px = H * W * pairs * (2 if "moments" in k else 1)
+    if "SQ_INSTS_VALU" in d:
+        e["valu_instructions_per_pixel"] = d["SQ_INSTS_VALU"] * 64 / px
+        e["all_counted_instructions_per_pixel"] = sum(d.get(c, 0.0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")) * 64 / px
+    out["per_kernel"][k] = e
+json.dump(out, open(os.path.join(DST, "r04_traffic.json"), "w"), indent=1)
+print("wrote r04_traffic.json", out["hbm_bytes_per_launch"])
+
+# ---- IDT: HBM bytes per launch of its kernels (same gfx950 correction)
+idt = defaultdict(dict)
+for sub in ("idt_FETCH_SIZE", "idt_WRITE_SIZE"):
+    if os.path.isdir(os.path.join(SRC, sub)):
+        for k, d in counters(sub).items():
+            if "idt_" in k:
+                idt[k.split("ct::")[-1].split("(")[0].replace("void ", "")].update(d)
+if idt:
+    o = {**STAMPS, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/bench_idt.py (one pair per call and 16 per call mixed: per-launch means)",
+         "correction": out["correction"], "per_kernel": {}}
+    for k, d in idt.items():
+        e = dict(d)
+        if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            e["read_bytes_mean_per_launch"], e["write_bytes_mean_per_launch"] = int(2 * d["FETCH_SIZE"] * 1024), int(d["WRITE_SIZE"] * 1024)
+        o["per_kernel"][k] = e
+    json.dump(o, open(os.path.join(DST, "r04_idt_traffic.json"), "w"), indent=1)
+    print("wrote r04_idt_traffic.json")
+
+# ---- MFMA-busy of the CNN forwards: summarised on the GPU box from ONE run each (tools/summarize_pmc.py there)
+for a, b in (("dcmcs3di_1080p_mfma_pmc.json", "r04_dcmcs3di_1080p_mfma_pmc.json"), ("gmflow_960x540_mfma_pmc.json", "r04_gmflow_960x540_mfma_pmc.json")):
+    p = os.path.join(SRC, a)
+    if os.path.exists(p) and os.path.getsize(p):
+        j = json.load(open(p))
+        assert j.get("source_stamp") == STAMP and not j.get("_ignored_runs"), (a, j.get("source_stamp"), j.get("_ignored_runs"))
+        j.update(STAMPS)
+        json.dump(j, open(os.path.join(DST, b), "w"), indent=1, sort_keys=True)
+        print("wrote", b, j["_all_kernels"])
+
+# ---- the persistent launch: kernel stats + HBM bytes per launch (float32 and uint8 instantiations)
+stats_csv("trace_persist", "r04_reinhard_persist_kernel_stats.csv")
+pp = defaultdict(dict)
+for sub in ("persist_FETCH_SIZE", "persist_WRITE_SIZE"):
+    if os.path.isdir(os.path.join(SRC, sub)):
+        for k, d in counters(sub).items():
+            if "reinhard_persist_kernel" in k:
+                pp[k.split("ct::rp::")[-1].split("(")[0]].update(d)
+if pp:
+    o = {**STAMPS, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/bench_reinhard_persist.py (16 pairs of 1080p per launch, PSNR fused)",
+         "correction": out["correction"], "per_kernel": {}}
+    for k, d in pp.items():
+        e = dict(d)
+        if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            e["read_bytes_per_launch"], e["write_bytes_per_launch"] = int(2 * d["FETCH_SIZE"] * 1024), int(d["WRITE_SIZE"] * 1024)
+            in_b = 4 if "float" in k else 1
+            e["algorithmic_bytes_per_launch"] = 16 * H * W * 3 * (3 * in_b + 4)        # target, reference, ground truth in; float32 result out
+            e["traffic_over_algorithmic"] = (e["read_bytes_per_launch"] + e["write_bytes_per_launch"]) / e["algorithmic_bytes_per_launch"]
+        o["per_kernel"][k] = e
+    json.dump(o, open(os.path.join(DST, "r04_reinhard_persist_traffic.json"), "w"), indent=1)
+    print("wrote r04_reinhard_persist_traffic.json")
