@@ -85,13 +85,19 @@ static IdtLayout idt_layout(void *ws, int batch, int n_iter, int bins) {
 // scalar registers, and min/max are float64 v_min/v_max (a 64-bit integer max is a compare + two selects); the
 // order-preserving keys that the integer atomicMax needs are built once per lane at the end.  A non-finite projection
 // poisons the range (NaN), as np.histogram's range check does in the reference.
+// grid = (G, batch, 2): blockIdx.z = 0 sweeps the target (iteration 0's rotation only: later iterations get their lo / hi from the
+// apply sweep before them), blockIdx.z = 1 the reference (the rotations of all iterations) -- one launch instead of two.
 template <typename T, int MAXROT>
-__global__ __launch_bounds__(kIdtBlock) void idt_minmax_kernel(const T *__restrict__ img, int64_t n, const double *__restrict__ rot,
-                                                               int n_iter, int it0, int n_rot, int which,
+__global__ __launch_bounds__(kIdtBlock) void idt_minmax_kernel(const T *__restrict__ tgt_img, int64_t n_tgt, const T *__restrict__ ref_img,
+                                                               int64_t n_ref, const double *__restrict__ rot, int n_iter,
                                                                unsigned long long *__restrict__ mm) {
     constexpr int RG = 4;               // rotations per sweep
     __shared__ unsigned long long lds[4 * 6 * RG];
     const int b = blockIdx.y;
+    const int which = blockIdx.z;
+    const T *img = which ? ref_img : tgt_img;
+    const int64_t n = which ? n_ref : n_tgt;
+    const int it0 = 0, n_rot = which ? n_iter : 1;
     const T *p = img + (size_t)b * n * 3;
     const bool vec = (reinterpret_cast<uintptr_t>(p) & 15) == 0;
     const int64_t n_chunks = n >> 2;
@@ -533,15 +539,13 @@ static int idt_impl(const T *target, int64_t n_t, const T *reference, int64_t n_
     // the lo/hi sweeps end in 6 * rotations same-address 64-bit atomicMax per workgroup, which serialise in L2 (~20 ns each):
     // with 2048 workgroups that tail was 40 of the sweep's 45 us -- one workgroup per CU keeps it under 5 us
     const int gmm_t = idt_minmax_grid(n_t, batch), gmm_r = idt_minmax_grid(n_r, batch);
-    // reference: lo/hi of every iteration's projection in one go; target: iteration 0 only
-    if (n_r > 0) {
-        hipLaunchKernelGGL((idt_minmax_kernel<T, 8>), dim3(gmm_r, batch), dim3(kIdtBlock), 0, s, reference, n_r, rot, n_iter, 0,
-                           n_iter, 1, l.mm);
+    // reference: lo/hi of every iteration's projection in one go; target: iteration 0 only -- both in ONE launch (blockIdx.z)
+    {
+        const int gmm = gmm_t > gmm_r ? gmm_t : gmm_r;
+        hipLaunchKernelGGL((idt_minmax_kernel<T, 8>), dim3(gmm, batch, n_r > 0 ? 2 : 1), dim3(kIdtBlock), 0, s, target, n_t, reference, n_r, rot,
+                           n_iter, l.mm);
         CT_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL((idt_minmax_kernel<T, 8>), dim3(gmm_t, batch), dim3(kIdtBlock), 0, s, target, n_t, rot, n_iter, 0, 1, 0,
-                       l.mm);
-    CT_CHECK_LAUNCH();
     // the histogram flush is 6*bins global integer atomics per workgroup onto the SAME addresses: keep the grid at
     // ~2 workgroups per CU (contended same-address atomics are an order of magnitude slower, MI355X_MICROARCH.md)
     int gh = idt_grid((n_t > n_r ? n_t : n_r) / 4 + 1, batch);
