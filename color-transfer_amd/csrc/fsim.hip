@@ -6,16 +6,12 @@
 // mean.  piq is third-party and absent offline: the arithmetic is restated from its published source (oracle/metrics.py
 // names the functions) -- "parity unpinned".
 //
-// Per call and image: one forward and 16 inverse 2-D FFTs of the pooled luminance (hipFFT, batched, work area in the
-// caller's workspace, plans cached per size), everything else hand-written kernels: pooling + YIQ, Scharr, spectrum x
+// Per call and image: one forward and 16 inverse 2-D FFTs of the pooled luminance (csrc/fft2d.hip: hand-written batched
+// mixed-radix Stockham transforms in LDS, no plan, no state -- hipFFT until round 3), around them: pooling + YIQ, Scharr, spectrum x
 // filter bank, an exact median (3-pass radix select on the float bit patterns; torch.median's lower median) of the
 // smallest-scale energy per orientation for the noise threshold, the phase-congruency map, the similarity / score
 // reduction (float64 partial sums, fixed order).  The filter bank and its three noise constants per orientation depend on
 // the pooled size only: ct_fsim_setup_f32 builds them once on the device.  float32 arithmetic like the reference.
-#include <hipfft/hipfft.h>
-
-#include <mutex>
-
 #include "ct_common.h"
 
 namespace ct {
@@ -23,50 +19,9 @@ namespace ct {
 constexpr int kFsO = 4, kFsS = 4, kFsK = kFsO * kFsS;
 constexpr double kPi = 3.14159265358979323846;
 
-struct FsimPlan {
-    int hp, wp, batch;
-    hipfftHandle fwd, inv;
-    size_t work;
-};
-constexpr int kFsMaxPlans = 16;
-static FsimPlan g_plans[kFsMaxPlans];
-static int g_n_plans = 0;
-static std::mutex g_plan_mutex;
-static std::mutex g_exec_mutex;     // a cached hipFFT plan carries its stream and work area: set + execute sequences are serialised
-
-// plans for `batch` luminance images (forward) and batch * 16 filtered spectra (inverse); work area supplied per call.
-// Returns a COPY of the cache entry (handles are plain values; the table may be reshuffled by the next call).
-// Callers hold g_exec_mutex from before this call until their last hipFFT call (lock order: exec, then plan).
-static bool fsim_plan(int hp, int wp, int batch, FsimPlan *out) {
-    std::lock_guard<std::mutex> lock(g_plan_mutex);
-    for (int i = 0; i < g_n_plans; ++i)
-        if (g_plans[i].hp == hp && g_plans[i].wp == wp && g_plans[i].batch == batch) { *out = g_plans[i]; return true; }
-    if (g_n_plans == kFsMaxPlans) {                // recycle the oldest entry; its transforms may still be in flight.  The
-        (void)hipDeviceSynchronize();              // caller holds g_exec_mutex, so no other thread is between look-up and execute
-        hipfftDestroy(g_plans[0].fwd);
-        hipfftDestroy(g_plans[0].inv);
-        for (int i = 1; i < kFsMaxPlans; ++i) g_plans[i - 1] = g_plans[i];
-        g_n_plans = kFsMaxPlans - 1;
-    }
-    FsimPlan p;
-    p.hp = hp; p.wp = wp; p.batch = batch;
-    int n[2] = {hp, wp};
-    size_t w1 = 0, w2 = 0;
-    if (hipfftCreate(&p.fwd) != HIPFFT_SUCCESS) return false;
-    if (hipfftCreate(&p.inv) != HIPFFT_SUCCESS) { hipfftDestroy(p.fwd); return false; }
-    hipfftSetAutoAllocation(p.fwd, 0);
-    hipfftSetAutoAllocation(p.inv, 0);
-    if (hipfftMakePlanMany(p.fwd, 2, n, nullptr, 1, hp * wp, nullptr, 1, hp * wp, HIPFFT_C2C, batch, &w1) != HIPFFT_SUCCESS ||
-        hipfftMakePlanMany(p.inv, 2, n, nullptr, 1, hp * wp, nullptr, 1, hp * wp, HIPFFT_C2C, batch * kFsK, &w2) != HIPFFT_SUCCESS) {
-        hipfftDestroy(p.fwd);                      // no handle leaks when a plan cannot be made
-        hipfftDestroy(p.inv);
-        return false;
-    }
-    p.work = w1 > w2 ? w1 : w2;
-    g_plans[g_n_plans++] = p;
-    *out = p;
-    return true;
-}
+// csrc/fft2d.hip: batched in-place 2-D complex DFT (hand-written; hipFFT until round 3), sign -1 forward / +1 backward, unnormalised
+int fft2d_c2c(float2 *data, int hp, int wp, int planes, int sign, hipStream_t s);
+bool fft2d_supported(int hp, int wp);
 
 struct FsimLayout {
     float2 *lum;          // [imgs][P]        luminance as complex -> its spectrum
@@ -78,14 +33,13 @@ struct FsimLayout {
     unsigned int *sel;    // [imgs * 4][2]   (prefix, remaining rank)
     float *thr;           // [imgs * 4]      noise threshold T per orientation
     double *part;         // [pairs][blocks][2]
-    void *fft_work;
     size_t total;
 };
 constexpr int kFsScoreBlocks = 64;
 
 static size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-static FsimLayout fsim_layout(void *ws, int imgs, int P, size_t fft_work) {
+static FsimLayout fsim_layout(void *ws, int imgs, int P) {
     FsimLayout l;
     char *p = reinterpret_cast<char *>(ws);
     size_t o = 0;
@@ -98,7 +52,6 @@ static FsimLayout fsim_layout(void *ws, int imgs, int P, size_t fft_work) {
     l.sel = reinterpret_cast<unsigned int *>(p + o); o += up256((size_t)imgs * kFsO * 2 * sizeof(unsigned int));
     l.thr = reinterpret_cast<float *>(p + o); o += up256((size_t)imgs * kFsO * sizeof(float));
     l.part = reinterpret_cast<double *>(p + o); o += up256((size_t)(imgs / 2 + 1) * kFsScoreBlocks * 2 * sizeof(double));
-    l.fft_work = p + o; o += up256(fft_work);
     l.total = o;
     return l;
 }
@@ -369,13 +322,8 @@ int ct_fsim_pooled_size(int h, int w, int *hp, int *wp) {
 size_t ct_fsim_workspace_bytes(int batch, int h, int w) {
     if (batch < 1 || h < 1 || w < 1) return 0;
     const int f = ct::fsim_factor(h, w), hp = h / f, wp = w / f;
-    if (hp < 2 || wp < 2) return 0;
-    std::lock_guard<std::mutex> exec_lock(ct::g_exec_mutex);    // plan creation may evict a plan another thread is about to run
-    ct::FsimPlan pl, ps;
-    if (!ct::fsim_plan(hp, wp, 2 * batch, &pl)) return 0;
-    if (!ct::fsim_plan(hp, wp, 1, &ps)) return 0;            // the setup call runs the 16-image inverse plan of batch 1
-    const size_t work = pl.work > ps.work ? pl.work : ps.work;
-    return ct::fsim_layout(nullptr, 2 * batch, hp * wp, work).total;
+    if (hp < 2 || wp < 2 || !ct::fft2d_supported(hp, wp)) return 0;
+    return ct::fsim_layout(nullptr, 2 * batch, hp * wp).total;
 }
 
 // filters: [16][hp*wp] float32 (orientation-major), consts: [4][3] float64; both on the device, valid for every frame of this size
@@ -383,11 +331,8 @@ int ct_fsim_setup_f32(int h, int w, float *filters, double *consts, void *ws, si
     if (!filters || !consts || !ws || h < 1 || w < 1 || (reinterpret_cast<uintptr_t>(ws) & 255)) return CT_E_BADARG;
     const int f = ct::fsim_factor(h, w), hp = h / f, wp = w / f, P = hp * wp;
     if (hp < 2 || wp < 2) return CT_E_BADARG;
-    std::lock_guard<std::mutex> exec_lock(ct::g_exec_mutex);
-    ct::FsimPlan plan;
-    if (!ct::fsim_plan(hp, wp, 1, &plan)) return CT_E_BADARG;
-    const ct::FsimPlan *pl = &plan;
-    const ct::FsimLayout l = ct::fsim_layout(ws, 2, P, pl->work);
+    if (!ct::fft2d_supported(hp, wp)) return CT_E_BADARG;
+    const ct::FsimLayout l = ct::fsim_layout(ws, 2, P);
     if (ws_bytes < l.total) return CT_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(ct::fsim_filters_kernel, dim3((P + 255) / 256), dim3(256), 0, s, filters, hp, wp);
@@ -395,8 +340,7 @@ int ct_fsim_setup_f32(int h, int w, float *filters, double *consts, void *ws, si
     const size_t n = (size_t)ct::kFsK * P;
     hipLaunchKernelGGL(ct::fsim_filters_to_complex_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float *)filters, l.eo, n);
     CT_CHECK_LAUNCH();
-    if (hipfftSetStream(pl->inv, s) != HIPFFT_SUCCESS || hipfftSetWorkArea(pl->inv, l.fft_work) != HIPFFT_SUCCESS) return CT_E_BADARG;
-    if (hipfftExecC2C(pl->inv, (hipfftComplex *)l.eo, (hipfftComplex *)l.eo, HIPFFT_BACKWARD) != HIPFFT_SUCCESS) return CT_E_BADARG;
+    { const int rc = ct::fft2d_c2c(l.eo, hp, wp, ct::kFsK, +1, s); if (rc) return rc; }
     hipLaunchKernelGGL(ct::fsim_consts_kernel, dim3(ct::kFsO), dim3(256), 0, s, (const float *)filters, (const float2 *)l.eo, P, consts);
     CT_CHECK_LAUNCH();
     return CT_OK;
@@ -409,11 +353,8 @@ int ct_frame_fsim_f32(const float *a, const float *b, double *out, int batch, in
     if (batch == 0) return CT_OK;
     const int f = ct::fsim_factor(h, w), hp = h / f, wp = w / f, P = hp * wp, imgs = 2 * batch;
     if (hp < 2 || wp < 2 || imgs * ct::kFsO > 65535) return CT_E_BADARG;
-    std::lock_guard<std::mutex> exec_lock(ct::g_exec_mutex);
-    ct::FsimPlan plan;
-    if (!ct::fsim_plan(hp, wp, imgs, &plan)) return CT_E_BADARG;
-    const ct::FsimPlan *pl = &plan;
-    const ct::FsimLayout l = ct::fsim_layout(ws, imgs, P, pl->work);
+    if (!ct::fft2d_supported(hp, wp)) return CT_E_BADARG;
+    const ct::FsimLayout l = ct::fsim_layout(ws, imgs, P);
     if (ws_bytes < l.total) return CT_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const dim3 gp((P + 255) / 256, imgs);
@@ -423,12 +364,10 @@ int ct_frame_fsim_f32(const float *a, const float *b, double *out, int batch, in
     CT_CHECK_LAUNCH();
     hipLaunchKernelGGL(ct::fsim_grad_kernel, gp, dim3(256), 0, s, (const float2 *)l.lum, hp, wp, l.grad);
     CT_CHECK_LAUNCH();
-    if (hipfftSetStream(pl->fwd, s) != HIPFFT_SUCCESS || hipfftSetWorkArea(pl->fwd, l.fft_work) != HIPFFT_SUCCESS) return CT_E_BADARG;
-    if (hipfftExecC2C(pl->fwd, (hipfftComplex *)l.lum, (hipfftComplex *)l.lum, HIPFFT_FORWARD) != HIPFFT_SUCCESS) return CT_E_BADARG;
+    { const int rc = ct::fft2d_c2c(l.lum, hp, wp, imgs, -1, s); if (rc) return rc; }
     hipLaunchKernelGGL(ct::fsim_apply_filters_kernel, gp, dim3(256), 0, s, (const float2 *)l.lum, filters, P, l.eo);
     CT_CHECK_LAUNCH();
-    if (hipfftSetStream(pl->inv, s) != HIPFFT_SUCCESS || hipfftSetWorkArea(pl->inv, l.fft_work) != HIPFFT_SUCCESS) return CT_E_BADARG;
-    if (hipfftExecC2C(pl->inv, (hipfftComplex *)l.eo, (hipfftComplex *)l.eo, HIPFFT_BACKWARD) != HIPFFT_SUCCESS) return CT_E_BADARG;
+    { const int rc = ct::fft2d_c2c(l.eo, hp, wp, imgs * ct::kFsK, +1, s); if (rc) return rc; }
     // exact lower median of the scale-0 energy per (image, orientation): 11 + 11 + 10 key bits
     const int planes = imgs * ct::kFsO;
     int hb = (P + 256 * 8 - 1) / (256 * 8);

@@ -462,6 +462,7 @@ def frame_icid(a, b):
 
 
 SIGNATURES.update({
+    "ct_fft2d_c2c_f32": (_c_int, [_c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "ct_fsim_pooled_size": (_c_int, [_c_int, _c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "ct_fsim_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
     "ct_fsim_setup_f32": (_c_int, [_c_int, _c_int, _c_p, _c_p, _c_p, _c_sz, _c_p]),
@@ -469,6 +470,18 @@ SIGNATURES.update({
 })
 _fsim_tables = {}                                  # (device, h, w) -> (filters [16, hp*wp] float32, consts [4, 3] float64)
 CT_WS_FSIM = -7
+
+
+def fft2d_(x, inverse=False):
+    """In-place batched 2-D DFT of a complex64 tensor [..., H, W] (csrc/fft2d.hip; the transform inside frame_fsim): torch.fft.fft2,
+    or -- inverse=True -- torch.fft.ifft2 without its 1 / (H W)."""
+    if not x.is_cuda or x.dtype != torch.complex64 or not x.is_contiguous() or x.dim() < 2:
+        raise CtHipError("fft2d_ needs a contiguous complex64 device tensor [..., H, W]")
+    _check_device(x)
+    h, w = x.shape[-2], x.shape[-1]
+    planes = x.numel() // (h * w) if h * w else 0
+    check(lib().ct_fft2d_c2c_f32(_ptr(x), h, w, planes, 1 if inverse else 0, _stream()))
+    return x
 
 
 def _fsim_ws(device, batch, h, w):

@@ -436,8 +436,13 @@ int ct_fb_check_f32(const float *fwd, const float *bwd, const float *warped_bwd,
  *   unpinned).  ct_fsim_setup_f32 builds, once per frame size, the log-Gabor filter bank ([16][hp*wp] float32,
  *   orientation-major; hp x wp = ct_fsim_pooled_size) and its three noise constants per orientation ([4][3] float64) on
  *   the device; ct_frame_fsim_f32 scores `batch` frames [batch][3][h][w] in [0,1]: out[b] float64.  The 1 + 16 FFTs per
- *   image run in hipFFT (plans cached per size inside the library, work area inside ws); ws: 256-byte aligned,
- *   ct_fsim_workspace_bytes(batch, h, w).                                                                            */
+ *   image run in this library's own batched 2-D transform (ct_fft2d_c2c_f32 below; no vendor FFT, no plan, no state);
+ *   ws: 256-byte aligned, ct_fsim_workspace_bytes(batch, h, w) (0: pooled frame beyond 4096 points on an axis).       */
+/* Batched in-place 2-D complex DFT (csrc/fft2d.hip): `planes` planes [hp][wp] of interleaved (re, im) float32 -- what
+ *   torch.fft.fft2 (inverse = 0) and torch.fft.ifft2 x hp x wp (inverse = 1: unnormalised) compute inside piq.fsim.  Mixed-radix
+ *   Stockham transforms of whole lines in LDS (radices 4, 2, 3, 5 in registers, any other prime factor as a plain butterfly):
+ *   every size with both axes <= 4096; asynchronous, no workspace.                                                    */
+int ct_fft2d_c2c_f32(void *data, int hp, int wp, int planes, int inverse, void *stream);
 int ct_fsim_pooled_size(int h, int w, int *hp, int *wp);
 size_t ct_fsim_workspace_bytes(int batch, int h, int w);
 int ct_fsim_setup_f32(int h, int w, float *filters, double *consts, void *ws, size_t ws_bytes, void *stream);

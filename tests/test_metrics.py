@@ -184,3 +184,26 @@ def test_fused_reinhard_psnr(hip, mode):
         assert torch.equal(out, want)
         assert torch.allclose(ps, want_ps, rtol=1e-6, atol=0), (ps, want_ps)          # float32 per-tile partial sums vs float64
         assert torch.allclose(ps[:, 1].cpu(), om.psnr(out.cpu(), g.cpu()), atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(270, 480), (256, 256), (135, 240), (2, 2), (1, 7), (17, 31), (64, 96), (45, 30), (97, 101), (8, 1),
+                                   (540, 960), (250, 77), (1024, 4096), (3, 2 * 3 * 5 * 7 * 11)])
+def test_fft2d_vs_torch(hip, shape):
+    """csrc/fft2d.hip (the hand-written transform inside FSIM) against torch.fft in float64: every radix path -- 4 / 2 / 3 / 5 in
+    registers, other primes (7, 11, 31, 97, 101) as plain butterflies, prime lengths, single rows / columns -- forward and
+    unnormalised inverse, batched; error relative to the spectrum's largest magnitude."""
+    h, w = shape
+    g = torch.Generator().manual_seed(h * 1000 + w)
+    b = 3 if h * w < 300000 else 1
+    x = torch.complex(torch.randn(b, h, w, generator=g), torch.randn(b, h, w, generator=g)).to(torch.complex64)
+    for inverse in (False, True):
+        got = hip.fft2d_(x.cuda().clone(), inverse=inverse).cpu().to(torch.complex128)
+        want = torch.fft.ifft2(x.to(torch.complex128)) * (h * w) if inverse else torch.fft.fft2(x.to(torch.complex128))
+        err = (got - want).abs().max().item() / want.abs().max().item()
+        assert err <= 2e-6, (shape, inverse, err)
+    # round trip: ifft2(fft2(x)) = h w x
+    y = hip.fft2d_(hip.fft2d_(x.cuda().clone()), inverse=True).cpu() / (h * w)
+    assert (y - x).abs().max().item() <= 5e-6 * x.abs().max().item()
+    with pytest.raises(hip.CtHipError):
+        hip.fft2d_(torch.zeros(1, 4, 5000, dtype=torch.complex64, device="cuda"))          # an axis beyond 4096 points
