@@ -34,6 +34,24 @@ inline int blocks_per_image(int64_t n_chunks, int n_images) {
         if (e__ != hipSuccess) return (int)e__;     \
     } while (0)
 
+// ---- zeroing workspace words on the launch stream ---------------------------------------------------------------------------
+// A kernel of this library instead of hipMemsetAsync: captured in a hipGraph (torch.cuda.graph), a memset node in front of a
+// kernel was seen not to have run when that kernel read the words on replay, once any other call of the entry had preceded
+// the capture (ROCm 7.2, round 4; csrc/reinhard_persist.hip found it: stale arrival counts, NaN results).  A kernel node
+// keeps the stream order.  p: 4-byte aligned, bytes a multiple of 4.
+static __global__ void ct_zero_words_kernel(unsigned int *__restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline int zero_async(void *p, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return 0;
+    const size_t n = (bytes + 3) / 4;
+    size_t g = (n + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(ct_zero_words_kernel, dim3((unsigned)g), dim3(256), 0, s, reinterpret_cast<unsigned int *>(p), n);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 // ---- 4-pixel (12 element) vector I/O of interleaved HWC data -------------------------------
 // A lane owns 4 whole pixels = 48 B (f32) / 96 B (f64) of contiguous memory, fetched as
 // 16-byte vectors.  `vec` = the image base is 16-byte aligned (wave-uniform).

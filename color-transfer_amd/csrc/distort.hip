@@ -105,7 +105,7 @@ int ct_distort_u8(const uint8_t *in, int height, int width, int kind, double par
     const int64_t n = (int64_t)height * width;
     hipStream_t s = (hipStream_t)stream;
     if (kind == ct::kDistContrast) {
-        if (hipMemsetAsync(ws, 0, 8, s) != hipSuccess) return (int)hipGetLastError();
+        { const int zr = ct::zero_async(ws, 8, s); if (zr) return zr; }
         const int blocks = (int)((n + ct::kBlock * 8 - 1) / (ct::kBlock * 8));
         hipLaunchKernelGGL(ct::gray_sum_kernel, dim3(blocks < 256 ? blocks : 256), dim3(ct::kBlock), 0, s, in, n, (unsigned long long *)ws);   // one same-address atomic per workgroup: keep them few
         CT_CHECK_LAUNCH();

@@ -359,7 +359,7 @@ int ct_frame_fsim_f32(const float *a, const float *b, double *out, int batch, in
     hipStream_t s = (hipStream_t)stream;
     const dim3 gp((P + 255) / 256, imgs);
     const float invP = 1.0f / (float)P;
-    if (hipMemsetAsync(l.hist, 0, (size_t)imgs * ct::kFsO * 2048 * sizeof(unsigned int), s) != hipSuccess) return (int)hipGetLastError();
+    { const int zr = ct::zero_async(l.hist, (size_t)imgs * ct::kFsO * 2048 * sizeof(unsigned int), s); if (zr) return zr; }
     hipLaunchKernelGGL(ct::fsim_prep_kernel, gp, dim3(256), 0, s, a, b, h, w, f, hp, wp, l.lum, l.iq);
     CT_CHECK_LAUNCH();
     hipLaunchKernelGGL(ct::fsim_grad_kernel, gp, dim3(256), 0, s, (const float2 *)l.lum, hp, wp, l.grad);

@@ -38,7 +38,7 @@ __device__ __forceinline__ double proj(const double *r, double x0, double x1, do
     return fma(r[2], x2, fma(r[1], x1, r[0] * x0));
 }
 
-// per (pair, iteration) workspace record, all zero-initialised by one hipMemsetAsync per call
+// per (pair, iteration) workspace record, all zero-initialised by one zeroing launch per call (ct_common.h: zero_async)
 // Same-address atomics from many workgroups serialise in the memory system (~20 ns each): the lo/hi keys and the histogram
 // counts are therefore kept in SHARDS (workgroup g updates shard g % S; readers take the max / the sum over the shards).
 // Integer max and integer add are order independent, so every bit of the result is unchanged; one pair's sweeps lose their
@@ -534,7 +534,7 @@ static int idt_impl(const T *target, int64_t n_t, const T *reference, int64_t n_
     hipError_t e;
     if (n_iter == 0) return CT_E_BADARG;   // the host returns the input untouched in that case
     if (n_t == 0) return CT_OK;
-    if ((e = hipMemsetAsync(ws, 0, l.zero_bytes, s)) != hipSuccess) return (int)e;
+    { const int zr = zero_async(ws, l.zero_bytes, s); if (zr) return zr; }
     const int gt = idt_apply_grid(n_t, batch);
     // the lo/hi sweeps end in 6 * rotations same-address 64-bit atomicMax per workgroup, which serialise in L2 (~20 ns each):
     // with 2048 workgroups that tail was 40 of the sweep's 45 us -- one workgroup per CU keeps it under 5 us

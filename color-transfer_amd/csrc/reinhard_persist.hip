@@ -721,7 +721,7 @@ bool eligible(int64_t n_pixels, bool any_size) {
     return on && slots >= kMaxWaves && slots <= 2 * kMaxParked;   // every wave has a tile, and at least half of them wait in LDS
 }
 
-static size_t rec_bytes(int batch) { return kErrBytes + (size_t)batch * kShards * kRecWords * sizeof(unsigned long long); }
+static size_t rec_bytes(int batch) { return kErrBytes + (size_t)batch * kShards * kRecWords * sizeof(unsigned long long); }    // a multiple of 16
 
 size_t ws_bytes(int64_t n_pixels, int batch) {
     if (!eligible(n_pixels, true) || batch <= 0) return 0;
@@ -774,8 +774,8 @@ int launch(const T *target, const T *reference, const T *gt, float *out, double 
         // the caller's records: [targets of the whole batch][references of the whole batch]
         a.stats_t = stats_out ? stats_out + (size_t)b0 * CT_LAB_STATS_STRIDE : nullptr;
         a.stats_r = stats_out ? stats_out + (size_t)(batch + b0) * CT_LAB_STATS_STRIDE : nullptr;
-        hipError_t e = hipMemsetAsync(base, 0, rec_bytes(b), stream);
-        if (e != hipSuccess) return (int)e;
+        // zeroed by a kernel, not by hipMemsetAsync (ct_common.h: a captured memset node did not keep the stream order on replay)
+        { const int zr = zero_async(base, rec_bytes(b), stream); if (zr) return zr; }
         if (ev_start && b0 == 0) (void)hipEventRecord(ev_start, stream);
         hipLaunchKernelGGL(kern, dim3(g), dim3(waves * kWave), lds, stream, a);
         CT_CHECK_LAUNCH();
