@@ -76,70 +76,81 @@ def cpu_baseline(n_pairs=4):
                       "median %.3f s/pair; host has %d cores" % (n_pairs, med, os.cpu_count() or 0)}
 
 
-def video_stream(n_frames, dtype, device, rank, world, pool_size=16):
+def video_stream(n_frames, dtype, device, rank, world, pool_size=8):
     """BASELINE.json configs[4] on this rank's share of an n_frames 1080p stereo video (frame f -> rank f % world): every
     frame triple (target, reference, ground truth) is UPLOADED from pinned host memory (the host buffers hand-over of the
-    drop-in boundary: PCIe is inside this measurement, unlike `value`), converted on the GPU if it is uint8, corrected by
-    methods.linear.color_transfer_between_images (one pair per call) and scored (PSNR fused into the apply sweep); the
-    [frames, 1] table is gathered with one collective at the end.  Uploads run on a copy stream, two frames ahead.
-    The host frames cycle through a pool of `pool_size` distinct pinned triples (decoding / generating 1000 distinct
-    frames on the host would measure the host: numpy's generator makes ~15 float frames/s)."""
+    drop-in boundary: PCIe is inside this measurement, unlike `value`), corrected by methods.linear.color_transfer_between_images
+    and scored (per-frame PSNR fused); the [frames, 1] table is gathered with one collective at the end.  Uploads run on a copy
+    stream, two uploads ahead of the kernels.  uint8 frames travel four triples per copy (74.6 MB, the size of ONE float32 triple:
+    single 18.7 MB copies reached 47.8 GB/s, float32 triples 53.4) and are corrected four pairs per call by ct_reinhard_psnr_u8,
+    which reads the bytes; float32 frames one triple per copy and call.  The host frames cycle through a pool of `pool_size`
+    distinct pinned chunks (decoding / generating 1000 distinct frames on the host would measure the host)."""
     import ct_hip
     from utils import sharding as sh
     np_dtype = np.uint8 if dtype == "u8" else np.float32
+    chunk = 4 if dtype == "u8" else 1
     pool = []
     for i in range(pool_size):
         rng = np.random.default_rng(4321 + i)
-        trip = rng.integers(0, 256, (3, H, W, 3), dtype=np.uint8)
+        trip = rng.integers(0, 256, (3, chunk, H, W, 3), dtype=np.uint8)          # [role][frame of the chunk][H][W][3]
         if dtype != "u8":
             trip = trip.astype(np.float32) / np.float32(255)
         pool.append(torch.from_numpy(np.ascontiguousarray(trip.astype(np_dtype))).pin_memory())
     mine = sh.frames_of_rank(n_frames, rank, world)
     n_local = len(mine)
+    n_chunks = (n_local + chunk - 1) // chunk
     copy_stream = torch.cuda.Stream(device=device)
     main = torch.cuda.current_stream(device)
     depth = 3
-    dev_raw = [torch.empty((3, H, W, 3), dtype=pool[0].dtype, device=device) for _ in range(depth)]
+    dev_raw = [torch.empty((3, chunk, H, W, 3), dtype=pool[0].dtype, device=device) for _ in range(depth)]
     uploaded = [torch.cuda.Event() for _ in range(depth)]
     consumed = [torch.cuda.Event() for _ in range(depth)]
-    out = torch.empty((1, H, W, 3), dtype=torch.float32, device=device)
-    rec = torch.zeros((max(n_local, 1), 2), dtype=torch.float64, device=device)
+    out = torch.empty((chunk, H, W, 3), dtype=torch.float32, device=device)
+    rec = torch.zeros((max(n_chunks * chunk, 1), 2), dtype=torch.float64, device=device)
 
-    def upload(i):
-        slot = i % depth
+    def frames_of(c):
+        return min(chunk, n_local - c * chunk)
+
+    def upload(c):
+        slot, k = c % depth, frames_of(c)
         with torch.cuda.stream(copy_stream):
-            if i >= depth:
-                copy_stream.wait_event(consumed[slot])          # the kernels that read this slot's previous frame are done
-            dev_raw[slot].copy_(pool[mine[i] % pool_size], non_blocking=True)
+            if c >= depth:
+                copy_stream.wait_event(consumed[slot])          # the kernels that read this slot's previous chunk are done
+            src = pool[mine[c * chunk] % pool_size]
+            if k == chunk:
+                dev_raw[slot].copy_(src, non_blocking=True)
+            else:                                               # ragged last chunk: only the frames that exist
+                dev_raw[slot][:, :k].copy_(src[:, :k], non_blocking=True)
             uploaded[slot].record(copy_stream)
 
-    def process(i):
-        slot = i % depth
+    def process(c):
+        slot, k = c % depth, frames_of(c)
         main.wait_event(uploaded[slot])
         src = dev_raw[slot]
+        r = rec[c * chunk:c * chunk + k]
         if dtype == "u8":
             # ct_reinhard_psnr_u8 reads the bytes: k / 255 (the reference's .float() / 255, utils/data.py:84,106,125) and its gamma
             # expansion come out of 256-entry tables inside the kernel -- no conversion pass, no torch kernel in the loop
-            ct_hip.reinhard_persist(src[0:1], src[1:2], gt=src[2:3], out=out, psnr_out=rec[i:i + 1])
+            ct_hip.reinhard_persist(src[0, :k], src[1, :k], gt=src[2, :k], out=out[:k], psnr_out=r)
         else:
-            ct_hip.reinhard_psnr(src[0:1], src[1:2], src[2:3], out=out, psnr_out=rec[i:i + 1])
+            ct_hip.reinhard_psnr(src[0, :k], src[1, :k], src[2, :k], out=out[:k], psnr_out=r)
         consumed[slot].record(main)
 
     # initialisation: code objects, clocks, the communicator
-    for i in range(min(depth, n_local)):
-        upload(i)
-    for i in range(min(depth, n_local)):
-        process(i)
+    for c in range(min(depth, n_chunks)):
+        upload(c)
+    for c in range(min(depth, n_chunks)):
+        process(c)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(min(depth - 1, n_local)):
-        upload(i)
-    for i in range(n_local):
-        if i + depth - 1 < n_local:
-            upload(i + depth - 1)
-        process(i)
+    for c in range(min(depth - 1, n_chunks)):
+        upload(c)
+    for c in range(n_chunks):
+        if c + depth - 1 < n_chunks:
+            upload(c + depth - 1)
+        process(c)
     table = sh.gather_frame_metrics(rec[:n_local, 1:2], n_frames, rank, world)
     if world > 1:
         dist.barrier()
@@ -152,10 +163,11 @@ def video_stream(n_frames, dtype, device, rank, world, pool_size=16):
     bytes_per_frame = 3 * H * W * 3 * pool[0].element_size()
     return {"frames": n_frames, "host_dtype": dtype, "frames_per_s": n_frames / dt, "ms_per_frame_per_gpu": dt / max(n_local, 1) * 1e3,
             "h2d_GB_per_s_per_gpu": bytes_per_frame * n_local / dt / 1e9, "h2d_bytes_per_frame": bytes_per_frame,
+            "frames_per_copy_and_call": chunk,
             "pcie_gen5_x16_GB_per_s": 63.0, "mean_psnr": float(table[:, 0].mean()),
             "entry": "ct_reinhard_psnr_u8 (persistent launch, reads the bytes)" if dtype == "u8" else "ct_reinhard_psnr_f32",
-            "note": "uploads (3 frames per stereo triple) on a copy stream two frames ahead, one pair per Reinhard call, PSNR fused, "
-                    "one gather; host frames from a pool of %d pinned triples" % pool_size}
+            "note": "uploads (3 frames per stereo triple, %d triple(s) per copy) on a copy stream two uploads ahead, %d pair(s) per Reinhard call, "
+                    "PSNR fused, one gather; host frames from a pool of %d pinned chunks" % (chunk, chunk, pool_size)}
 
 
 def main():
