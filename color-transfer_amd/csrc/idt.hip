@@ -194,10 +194,20 @@ __device__ __forceinline__ double idt_edge(int i, int bins, double lo, double hi
     return (i == bins) ? hi : ((double)i * step + lo);
 }
 
-// unique k with edges[k] <= x < edges[k+1] (last bin closed) == numpy's histogram bin
+// unique k with edges[k] <= x < edges[k+1] (last bin closed) == numpy's histogram bin.
+// The estimate (x - lo) * scale is right unless x sits within a rounding of an edge, so the common case is ONE check of the
+// estimate against its two edges (same edge arithmetic, same comparisons as numpy's correction); only a wave in which some
+// lane fails it -- an estimate that is off by one, x on the closed last edge, NaN -- runs the two correction rounds.  The
+// result is the correction's result in every case (it would not move a k that passes the check): bit-identical bin indices,
+// ~16 float64-rate instructions fewer per axis, pixel and sweep (round 4: the sweeps are bound by vector instruction issue).
 __device__ __forceinline__ int idt_bin(double x, int bins, double lo, double hi, double step, double scale) {
     int k = (int)((x - lo) * scale);
     k = k < 0 ? 0 : (k > bins - 1 ? bins - 1 : k);
+#ifndef CT_IDT_NO_FASTBIN
+    // k <= bins - 1: edge k is never the special last edge, and edge k + 1 only matters when it is not (k < bins - 1)
+    const bool settled = (x >= (double)k * step + lo) & ((k == bins - 1) | (x < (double)(k + 1) * step + lo));
+    if (__builtin_amdgcn_ballot_w64(!settled) == 0) return k;
+#endif
 #pragma unroll
     for (int rep = 0; rep < 2; ++rep) {
         if (x < idt_edge(k, bins, lo, hi, step)) k -= (k > 0);
