@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the fused Reinhard entries on 1080p pairs resident in HBM (HIP events, median of rounds).
-env: CT_HIP_REINHARD_PERSIST=0 -> the two-sweep kernels; CT_HIP_PERSIST_WAVES=8|16; CT_HIP_PERSIST_WGS=n.
+env: CT_HIP_REINHARD_PERSIST=1 -> the fused float32 entries take the persistent launch (default: the two sweeps); CT_HIP_PERSIST_WGS=n.
 usage: tools/bench_reinhard.py [pairs=16] [u8]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,7 +32,7 @@ def timed(fn, n=40, rounds=5):
         res.append(e0.elapsed_time(e1) / n * 1e-3)
     return float(np.median(res)), float(np.min(res))
 
-cfg = "persist=%s waves=%s" % (os.environ.get("CT_HIP_REINHARD_PERSIST", "1"), os.environ.get("CT_HIP_PERSIST_WAVES", "16"))
+cfg = "persist=%s" % os.environ.get("CT_HIP_REINHARD_PERSIST", "0")
 if u8:
     f_psnr = lambda: ct_hip.reinhard_persist(t, r, gt=gt, out=out, psnr_out=psnr)
     f_plain = lambda: ct_hip.reinhard_persist(t, r, out=out)
