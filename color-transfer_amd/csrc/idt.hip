@@ -326,24 +326,26 @@ __global__ __launch_bounds__(kIdtBlock) void idt_lut_kernel(const unsigned int *
         double *q = par + (((size_t)b * n_iter + it) * 3 + j) * 4;
         q[0] = lo; q[1] = hi; q[2] = step; q[3] = scale;
     }
-    // exact integer prefix sums of both histograms: each thread owns a contiguous segment (<= 4 bins for
-    // bins <= 1024), a Hillis-Steele scan over the 256 segment totals in LDS, then the segment is re-walked
-    __shared__ unsigned long long seg[2][kIdtBlock];
+    // exact integer prefix sums of both histograms: each thread owns a contiguous segment (<= 4 bins for bins <= 1024); the 256
+    // segment totals are scanned inside the waves with shuffles (no barrier) and the four wave totals through LDS (one barrier)
+    // instead of a Hillis-Steele scan with 16 barriers -- this kernel is a chain of latencies (one pair per call: 4 x 7 us of 230)
+    __shared__ unsigned long long wtot[2][kIdtBlock / kWave];
     const int per = (bins + kIdtBlock - 1) / kIdtBlock;
     const int b0 = threadIdx.x * per;
     unsigned long long s0 = 0, s1 = 0;
     for (int i = b0; i < b0 + per && i < bins; ++i) { s0 += h0[i]; s1 += h1[i]; }
-    seg[0][threadIdx.x] = s0; seg[1][threadIdx.x] = s1;
-    __syncthreads();
-    for (int off = 1; off < kIdtBlock; off <<= 1) {
-        unsigned long long a0 = 0, a1 = 0;
-        if ((int)threadIdx.x >= off) { a0 = seg[0][threadIdx.x - off]; a1 = seg[1][threadIdx.x - off]; }
-        __syncthreads();
-        seg[0][threadIdx.x] += a0; seg[1][threadIdx.x] += a1;
-        __syncthreads();
+    unsigned long long i0 = s0, i1 = s1;                  // inclusive scan over the lanes of the wave
+    const int lane_ = threadIdx.x & (kWave - 1), wv_ = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const unsigned long long a0 = __shfl_up(i0, off, kWave), a1 = __shfl_up(i1, off, kWave);
+        if (lane_ >= off) { i0 += a0; i1 += a1; }
     }
+    if (lane_ == kWave - 1) { wtot[0][wv_] = i0; wtot[1][wv_] = i1; }
+    __syncthreads();
+    for (int ww = 0; ww < wv_; ++ww) { i0 += wtot[0][ww]; i1 += wtot[1][ww]; }
     {
-        unsigned long long c0 = seg[0][threadIdx.x] - s0, c1 = seg[1][threadIdx.x] - s1;   // exclusive prefix of this segment
+        unsigned long long c0 = i0 - s0, c1 = i1 - s1;   // exclusive prefix of this segment
         for (int i = b0; i < b0 + per && i < bins; ++i) {
             c0 += h0[i]; cp0[i] = (double)c0;
             c1 += h1[i]; cp1[i] = (double)c1;
