@@ -205,3 +205,21 @@ def test_sharding_arithmetic():
     # single process: identity
     m = torch.arange(12, dtype=torch.float64).reshape(6, 2)
     assert torch.equal(sh.gather_frame_metrics(m, 6, rank=0, world=1), m)
+
+
+def test_persistent_reinhard_entries_reject_bad_arguments_without_a_gpu():
+    """argument checks of the round-4 entries return before anything touches the device"""
+    import ct_hip
+    lib = ct_hip.lib()
+    assert lib.ct_reinhard_persist_supported(255) == 0 and lib.ct_reinhard_persist_supported(1920 * 1080) == 1
+    assert lib.ct_reinhard_persist_supported(64 * 1024 * 1024) == 0
+    assert lib.ct_workspace_bytes(ct_hip.CT_WS_REINHARD_PERSIST, 255, 4) == 0
+    assert lib.ct_workspace_bytes(ct_hip.CT_WS_REINHARD_PERSIST, 1920 * 1080, 4) > 0
+    assert lib.ct_workspace_bytes(ct_hip.CT_WS_REINHARD, 1920 * 1080, 4) >= lib.ct_workspace_bytes(ct_hip.CT_WS_REINHARD_PERSIST, 1920 * 1080, 4)
+    null = None
+    for fn in (lib.ct_reinhard_persist_f32, lib.ct_reinhard_psnr_u8):
+        assert fn(null, null, null, null, null, 1920 * 1080, 1, null, null, 0, null) == -1        # null images
+        assert fn(null, null, null, null, null, 1920 * 1080, 0, null, null, 0, null) == 0         # an empty batch is a no-op
+        assert fn(null, null, null, null, null, -1, 1, null, null, 0, null) == -1
+    assert lib.ct_fft2d_c2c_f32(null, 4, 4, 1, 0, null) == -1
+    assert lib.ct_set_lab_mode_thread(7) == -1 and lib.ct_set_lab_mode_thread(-1) == 0

@@ -265,3 +265,22 @@ def test_beside_another_streams_work(hip):
         assert torch.equal(got_o, want_o) and torch.equal(got_p, want_p)
     side.synchronize()
     del b
+
+
+def test_more_pairs_than_one_launch_holds(hip):
+    """batches beyond 64 pairs run as several launches (the pivots of 2 x 64 images live in LDS): same results as pair by pair, the
+    caller's statistics records [targets of the whole batch][references of the whole batch] filled across the launches"""
+    rng = np.random.default_rng(70)
+    B, n = 70, 3000
+    t = rng.random((B, n, 1, 3), dtype=np.float32)
+    r = (rng.random((B, n, 1, 3), dtype=np.float32) * np.linspace(0.2, 1.0, B, dtype=np.float32)[:, None, None, None]).astype(np.float32)
+    g = rng.random((B, n, 1, 3), dtype=np.float32)
+    stats = torch.zeros((2 * B, 8), dtype=torch.float64, device="cuda")
+    out, psnr = hip.reinhard_persist(dev(t), dev(r), gt=dev(g), stats_out=stats, verify=True)
+    for b in (0, 63, 64, 69):
+        s1 = torch.zeros((2, 8), dtype=torch.float64, device="cuda")
+        o1, p1 = hip.reinhard_persist(dev(t[b:b + 1]), dev(r[b:b + 1]), gt=dev(g[b:b + 1]), stats_out=s1)
+        assert torch.equal(o1[0], out[b]) and torch.equal(p1[0], psnr[b])
+        assert torch.equal(s1[0], stats[b]) and torch.equal(s1[1], stats[B + b])
+        ref = olin.color_transfer_between_images(t[b], r[b])
+        assert np.abs(out[b].cpu().numpy() - ref).max() <= 1e-6           # 3000 pixels: the float32 moment terms are not averaged far down
