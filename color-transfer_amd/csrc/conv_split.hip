@@ -25,6 +25,7 @@ constexpr int kSpTH = 8;      // output rows per workgroup (two per wave)
 constexpr int kSpTW = 32;     // output columns per workgroup (= MFMA N)
 constexpr int kSpKC = 16;     // input channels per stage (= MFMA K)
 constexpr int kSpCUs = 256;
+constexpr int kSkErrWord = 1000;   // stream-K scratch: 32-bit word (of the 1024 flag words) counting consumers that gave up waiting
 
 // LDS-DMA: 64 lanes x 16 bytes from global straight into LDS at lds_addr + 16 * lane (no registers).  Issued through
 // inline asm on purpose: behind the builtin the compiler puts an s_waitcnt vmcnt(0) in front of every later LDS read
@@ -70,7 +71,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
     float *stg = reinterpret_cast<float *>(smem16 + NP * PSZ + WRING * WSLOT) + (threadIdx.x >> 6) * (32 * 32);
     float *mxw = reinterpret_cast<float *>(smem16 + NP * PSZ + WRING * WSLOT) + 4 * (32 * 32);   // F16: the waves' tile maxima
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, hl = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, nl = lane & 31, hl = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // in an SGPR: the loader wave's bookkeeping is a scalar branch away
     const size_t plane = (size_t)a.H * a.W;
     const unsigned int uplane = (unsigned int)plane;
     const int n_chunks = (a.cin + kSpKC - 1) / kSpKC;
@@ -87,17 +89,65 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
     auto tile_id = [&](int k) -> int {            // this workgroup's k-th (tile, group) index
         return xcd_order ? xcd_first + (int)(blockIdx.x >> 3) + k * wgs_per_xcd : (int)blockIdx.x + k * (int)gridDim.x;
     };
-    const int n_stages = my_tiles * n_chunks;
+    // ---- stream-K (F16 form; the launcher sets a.sk_ws when it pays): the launch's time is a staircase in units / resident
+    // workgroups (tools/bench_conv_quant.py: 512 units 100 us, 544 units 170 us), so instead of whole units a workgroup takes an
+    // equal share of its XCD's STAGES: positions [ra, rb) of the list (unit, chunk) of that XCD's contiguous unit range.  A share
+    // is at least one unit long, so a unit is cut at most once: into a head [0, c) and a tail [c, n_chunks) that belong to
+    // neighbouring workgroups.  A workgroup runs its head piece FIRST and leaves the unscaled float32 partial sums in its slot of
+    // a.sk_ws (write-through stores, then a flag); it runs its tail piece LAST, adds the neighbour's partial in the epilogue and
+    // clears the flag -- by then the neighbour, which started with that head, has long published it (workgroups are dispatched
+    // in index order, so the producer blockIdx - 8 is never behind a resident consumer).  Sums are added in a fixed order.
+    const bool sk = F16 && a.sk_ws != nullptr;
+    int sk_ufirst = 0, sk_ca = 0, sk_ulast = 0, sk_cbl = 0, sk_has_t = 0, sk_has_h = 0, sk_nf = 0, sk_f0 = 0, sk_first = 0, sk_stages = 0;
+    int sk_col_len = 1, sk_col_rem = 0;
+    if (sk) {
+        const int x = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
+        sk_first = (int)((long long)n_tiles * x / 8);
+        const int count = (int)((long long)n_tiles * (x + 1) / 8) - sk_first;
+        sk_col_len = count / wgs_per_xcd; sk_col_rem = count - sk_col_len * wgs_per_xcd;
+        const long long sx = (long long)count * n_chunks;
+        const int ra = (int)(sx * j / wgs_per_xcd), rb = (int)(sx * (j + 1) / wgs_per_xcd);
+        sk_stages = rb - ra;
+        sk_ufirst = ra / n_chunks; sk_ca = ra - sk_ufirst * n_chunks;
+        sk_ulast = (rb - 1) / n_chunks; sk_cbl = rb - sk_ulast * n_chunks;
+        sk_has_t = sk_ca > 0; sk_has_h = sk_cbl < n_chunks;
+        sk_nf = sk_ulast - sk_ufirst + 1 - sk_has_t - sk_has_h; sk_f0 = sk_ufirst + sk_has_t;
+    }
+    // a workgroup's work: segments = (unit, chunks [cb, ce)); kind 0: a whole unit, 1: a head piece (handed on), 2: a tail piece
+    const int n_seg = sk ? sk_nf + sk_has_t + sk_has_h : my_tiles;
+    const int n_stages = sk ? sk_stages : my_tiles * n_chunks;
     if (n_stages == 0) return;
+    struct SegCur { int seg, chunk, ce, unit; };
+    auto seg_kind = [&](int i) -> int { return !sk ? 0 : (sk_has_h && i == 0) ? 1 : (i - sk_has_h < sk_nf) ? 0 : 2; };
+    // position in the XCD's list -> unit: the list is the column-major reading of the row-major [.][wgs_per_xcd] unit matrix, so
+    // that workgroups j, j + 1, ... -- whose shares start about one column apart -- work on NEIGHBOURING units at the same time
+    // (the groups of one tile, adjacent tiles: shared input tiles and halos in the XCD's L2), as the strided order of the plain
+    // mode has it
+    auto sk_unit = [&](int p) -> int {
+        const int big = sk_col_rem * (sk_col_len + 1);
+        const int col = p < big ? p / (sk_col_len + 1) : sk_col_rem + (p - big) / sk_col_len;
+        const int row = p < big ? p - col * (sk_col_len + 1) : (p - big) - (col - sk_col_rem) * sk_col_len;
+        return sk_first + row * wgs_per_xcd + col;
+    };
+    auto seg_set = [&](SegCur &c, int i) {
+        const int kind = seg_kind(i);
+        c.seg = i;
+        c.ce = kind == 1 ? sk_cbl : n_chunks;
+        c.unit = !sk ? tile_id(i) : sk_unit(kind == 1 ? sk_ulast : kind == 2 ? sk_ufirst : sk_f0 + i - sk_has_h);
+        c.chunk = kind == 2 ? sk_ca : 0;
+    };
+    auto seg_next = [&](SegCur &c) {               // one stage on (stays on the last stage's successor at the very end)
+        if (++c.chunk == c.ce && c.seg + 1 < n_seg) seg_set(c, c.seg + 1);
+    };
 
     // ---- staging roles (fixed per thread) ----
     const bool unit = tid < NU;
     const int u_h = tid / (ROWS * 8), u_rem = tid - u_h * (ROWS * 8), u_row = u_rem >> 3, u_g = u_rem & 7;
     float4 pf4[8];
     float pfe[PFE > 0 ? PFE : 1];
-    auto fetch_tile = [&](int stage) {
-        const int k = stage / n_chunks, chunk = stage - k * n_chunks;
-        const int t = tile_id(k) / a.groups;
+    auto fetch_tile = [&](const SegCur &c) {
+        const int chunk = c.chunk;
+        const int t = c.unit / a.groups;
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
         const int x0 = tx * kSpTW, y0 = ty * kSpTH, c0 = chunk * kSpKC;
         // two-source input: a 16-channel chunk lies entirely in one of the tensors (cin1 % 16 == 0)
@@ -196,45 +246,53 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
     // every wave reads its fragments from there.  (Per-wave register loads would tie the weights to the input-tile
     // fetch through the in-order vmcnt counter: each weight wait would also wait for the HBM latency of the tile loads
     // issued before it; and an L2 round trip is several taps long.)  g = stage * TAPS + tap counts this workgroup's taps.
-    const uint4 *wp16 = reinterpret_cast<const uint4 *>(a.wp);
     const bool wloader = (wave == 3);
     const unsigned int wl_addr = (unsigned int)reinterpret_cast<uintptr_t>(wl);   // LDS byte address (low half of the flat address)
     const int n_gtaps = n_stages * TAPS;
-    // issue cursor (taps are issued strictly in order, so no divisions): tap within the stage, chunk, group, ring slot
-    int wi_tap = 0, wi_chunk = 0, wi_k = 0, wi_grp = (int)(tile_id(0) % a.groups), wi_slot = 0;
-    auto w_issue = [&](int /*g*/) {
-        const uint4 *src = wp16 + ((((size_t)wi_grp * n_chunks + wi_chunk) * TAPS + wi_tap) * NP * MT) * 64 + lane;
+    // issue cursor of the loader wave (taps are issued strictly in order): segment / chunk, tap within the stage, ring slot, and the
+    // byte offset of the tap's fragments -- (chunk, tap) are contiguous within a group, so it only steps, except at a new unit
+    SegCur wcur;
+    seg_set(wcur, 0);
+    int wi_tap = 0, wi_slot = 0;
+    auto w_unit_off = [&](const SegCur &c) -> unsigned long long {
+        return (((unsigned long long)(c.unit % a.groups) * n_chunks + c.chunk) * TAPS) * (unsigned long long)(NP * MT * 1024);
+    };
+    unsigned long long w_off = w_unit_off(wcur);
+    const char *wlane = reinterpret_cast<const char *>(a.wp) + lane * 16;
+#ifdef CT_SPLIT_ABL_NOW
+    int wi_n = 0;
+#endif
+    auto w_issue = [&]() {                                 // the loader wave only
+        const char *src = wlane + w_off;
         const unsigned int dst = wl_addr + (unsigned int)(wi_slot * WSLOT * 16);   // + 16 * lane is implied by the instruction
 #ifdef CT_SPLIT_ABL_NOW
-        if (wloader && wi_k == 0 && wi_chunk == 0) {       // diagnostic: only the first stage's weights are ever loaded
-#else
-        if (wloader) {                                     // the cursor below advances in every wave: it stays scalar
+        if (wi_n++ < TAPS)                                 // diagnostic: only the first stage's weights are ever loaded
 #endif
 #pragma unroll
-            for (int f = 0; f < NP * MT; ++f) glds16(src + f * 64, __builtin_amdgcn_readfirstlane(dst + f * 1024));
-        }
+        for (int f = 0; f < NP * MT; ++f) glds16(src + f * 1024, __builtin_amdgcn_readfirstlane(dst + f * 1024));
+        w_off += NP * MT * 1024;
         wi_slot = (wi_slot + 1 == WRING) ? 0 : wi_slot + 1;
         if (++wi_tap == TAPS) {
             wi_tap = 0;
-            if (++wi_chunk == n_chunks) {
-                wi_chunk = 0;
-                ++wi_k;
-                wi_grp = (int)(tile_id(wi_k) % a.groups);
-            }
+            const int seg0 = wcur.seg;
+            seg_next(wcur);
+            if (wcur.seg != seg0) w_off = w_unit_off(wcur);
         }
     };
     // before the barrier that ends tap g: the fragments of tap g+1 have landed (loads of later taps may be in flight)
     auto w_landed = [&](int g) {
-        const int ahead = min(n_gtaps - g - 2, WAHEAD - 1);   // taps issued after tap g+1 (their loads may still be in flight)
         // vmcnt(ahead * NP * MT): the counter has six bits, [3:0] and [15:14] of the immediate
 #define CT_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
+        if (g + WAHEAD < n_gtaps) {                            // all but the workgroup's last taps: WAHEAD - 1 taps were issued after tap g+1
+            CT_VMCNT((WAHEAD - 1) * NP * MT);
+            return;
+        }
+        const int ahead = n_gtaps - g - 2;                    // taps issued after tap g+1 (their loads may still be in flight)
         if constexpr (WAHEAD == 3) {
-            if (ahead >= 2) CT_VMCNT(2 * NP * MT);
-            else if (ahead == 1) CT_VMCNT(NP * MT);
+            if (ahead == 1) CT_VMCNT(NP * MT);
             else CT_VMCNT(0);
         } else {
             switch (ahead) {
-                case 6: CT_VMCNT(6 * NP * MT); break;
                 case 5: CT_VMCNT(5 * NP * MT); break;
                 case 4: CT_VMCNT(4 * NP * MT); break;
                 case 3: CT_VMCNT(3 * NP * MT); break;
@@ -257,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
 #endif
     f32x16s acc[RPW][MT];
     // phase stagger of the two co-resident workgroups (see conv_mfma_kernel)
-    if (my_tiles >= 2) {
+    if (n_stages >= 2 * n_chunks) {
         const unsigned int hw_wave_slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | ((4 - 1) << 11));   // HW_ID[3:0]
         if (hw_wave_slot & 1) {
             const int half_tile_cycles = n_chunks * TAPS * RPW * MT * 6 * 32 / 2;
@@ -284,8 +342,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
     auto tile_exp = [&]() {
         return __builtin_amdgcn_readfirstlane(sp16_scale_exp(fmaxf(fmaxf(mxw[0], mxw[1]), fmaxf(mxw[2], mxw[3])), 100));
     };
-    auto init_acc = [&](int k) {   // raw float4 rows of the skip tensor (or zeros); finish_acc() re-lays them out
-        const int tg = tile_id(k), t = tg / a.groups, grp = tg - t * a.groups;
+    auto init_acc = [&](int tg) {  // raw float4 rows of the skip tensor (or zeros) of unit tg; finish_acc() re-lays them out
+        const int t = tg / a.groups, grp = tg - t * a.groups;
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
         const float *__restrict__ res = res_in_acc ? a.residual + (size_t)n * a.res_bstride + (size_t)grp * COUTP * plane : nullptr;
         const int cout_g = a.cout - grp * COUTP;
@@ -324,24 +382,28 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
             }
     };
 
-    w_issue(0);
-    for (int g0 = 1; g0 < WAHEAD && g0 < n_gtaps; ++g0) w_issue(g0);
-    if (wloader) w_landed(-1);
-    fetch_tile(0);
+    if (wloader) {
+        for (int g0 = 0; g0 < WAHEAD && g0 < n_gtaps; ++g0) w_issue();
+        w_landed(-1);
+    }
+    SegCur cc;                     // the stage being computed (its successor's tile is fetched under its MFMAs)
+    seg_set(cc, 0);
+    fetch_tile(cc);
     if constexpr (F16) {
         note_max();
         __syncthreads();
         e_stage = tile_exp();
         store_tile(sp16_pow2i(e_stage));
     } else {
-        init_acc(0);
+        init_acc(cc.unit);
         store_tile(1.f);
     }
-    for (int stage = 0; stage < n_stages; ++stage) {
-        const int k = stage / n_chunks, chunk = stage - k * n_chunks;
-        const int grp = (int)(tile_id(k) % a.groups);
+    for (int stage = 0; stage < n_stages; ++stage, seg_next(cc)) {
+        const int seg_k = seg_kind(cc.seg);
+        const bool seg_first = (cc.chunk == (seg_k == 2 ? sk_ca : 0)), seg_last = (cc.chunk + 1 == cc.ce);
+        const int grp = cc.unit % a.groups;
         if constexpr (F16) {
-            if (chunk == 0) {
+            if (seg_first) {
 #pragma unroll
                 for (int q = 0; q < RPW; ++q)
 #pragma unroll
@@ -358,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
                         for (int r = 0; r < 16; ++r) acc[q][m][r] *= rs;
             }
             e_cur = e_stage;
-        } else if (chunk == 0) {
+        } else if (seg_first) {
             finish_acc();
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -430,8 +492,12 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
         for (int tap = 0; tap < TAPS; ++tap) {
             const bool last_tap = (tap + 1 == TAPS);
             const int g = stage * TAPS + tap;
-            if (g + WAHEAD < n_gtaps) w_issue(g + WAHEAD);   // its slot was last read in tap g-1: free since that barrier
-            if (tap == 0 && next_stage) fetch_tile(stage + 1);   // next halo tile: in flight under this stage's MFMAs
+            if (wloader && g + WAHEAD < n_gtaps) w_issue();  // tap g + WAHEAD; its slot was last read in tap g-1: free since that barrier
+            if (tap == 0 && next_stage) {                    // next halo tile: in flight under this stage's MFMAs
+                SegCur fc = cc;
+                seg_next(fc);
+                fetch_tile(fc);
+            }
             if (!last_tap) read_b(tap + 1, bn);
             mfma6(wl + (g % WRING) * WSLOT + lane, bc);
 #pragma unroll
@@ -443,9 +509,48 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
             if (!last_tap) __syncthreads();                  // weight slot g%4 is free, slot (g+1)%4 is published
             CT_PHASE(5);
         }
-        if (chunk + 1 == n_chunks) {
+        if (F16 && seg_last && seg_k == 1) {
+            // ---- stream-K hand-off: the head piece's partial sums, unscaled, [(q, m, r / 2)][thread] float2 into this workgroup's
+            // slot; write-through (agent-scope) stores, drained, then the flag
+            const int un = -(e_cur + a.w_exp);
+            unsigned long long *slot = reinterpret_cast<unsigned long long *>(a.sk_ws) + (size_t)blockIdx.x * (RPW * MT * 8 * 256) + tid;
+            static_assert(RPW == 2 && MT == 2, "block select below");
+#pragma unroll 1
+            for (int qm = 0; qm < RPW * MT; ++qm) {            // rolled, the block picked with selects (register pressure, code size)
+#pragma unroll
+                for (int r2 = 0; r2 < 8; ++r2) {
+                    const float v0 = qm == 0 ? acc[0][0][2 * r2] : qm == 1 ? acc[0][1][2 * r2] : qm == 2 ? acc[1][0][2 * r2] : acc[1][1][2 * r2];
+                    const float v1 = qm == 0 ? acc[0][0][2 * r2 + 1] : qm == 1 ? acc[0][1][2 * r2 + 1] : qm == 2 ? acc[1][0][2 * r2 + 1] : acc[1][1][2 * r2 + 1];
+                    const unsigned long long lo = __float_as_uint(__builtin_amdgcn_ldexpf(v0, un));
+                    const unsigned long long hi = __float_as_uint(__builtin_amdgcn_ldexpf(v1, un));
+                    __hip_atomic_store(slot + (qm * 8 + r2) * 256, lo | (hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) (void)__hip_atomic_exchange(a.sk_flags + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (seg_last) {
             // ---- epilogue: lane owns pixels (y0 + wave*RPW + q, x0+nl), channels (r&3)+8(r>>2)+4hl of each 32-tile ----
-            const int t = tile_id(k) / a.groups;
+            const bool take = F16 && seg_k == 2;      // stream-K tail piece: the neighbour's head partial is added below
+            const unsigned long long *part = nullptr;
+            if (take) {
+                if (tid == 0) {
+                    // bounded (1 s of s_memrealtime at 100 MHz): a producer that never shows up -- it cannot happen while all
+                    // workgroups of the launch are resident -- costs a wrong tile and a count in the error word, not a hung queue
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    bool seen;
+                    while (!(seen = __hip_atomic_load(a.sk_flags + (blockIdx.x - 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) &&
+                           __builtin_amdgcn_s_memrealtime() - t0 < 100000000ull)
+                        __builtin_amdgcn_s_sleep(4);
+                    if (!seen) (void)__hip_atomic_fetch_add(a.sk_flags + kSkErrWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    (void)__hip_atomic_exchange(a.sk_flags + (blockIdx.x - 8), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
+                }
+                __syncthreads();
+                // read below with agent-scope loads (they bypass this XCD's L2 for these addresses only); an acquire fence would
+                // invalidate the whole L2 under the other workgroups' input tiles and weights
+                part = reinterpret_cast<const unsigned long long *>(a.sk_ws) + (size_t)(blockIdx.x - 8) * (RPW * MT * 8 * 256) + tid;
+            }
+            const int t = cc.unit / a.groups;
             const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
             float *__restrict__ out = a.out + (size_t)n * a.out_bstride + (size_t)grp * COUTP * plane;
             const float *__restrict__ res = a.residual ? a.residual + (size_t)n * a.res_bstride + (size_t)grp * COUTP * plane : nullptr;
@@ -507,6 +612,15 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
                         for (int r = 0; r < 16; ++r) {
                             const int ch = (r & 3) + 8 * (r >> 2) + 4 * hl;
                             stg[ch * 32 + nl] = __builtin_amdgcn_ldexpf(blk[r], un) + bias_g[m * 32 + ch];
+                        }
+                        if (take) {
+#pragma unroll
+                            for (int r2 = 0; r2 < 8; ++r2) {
+                                const unsigned long long pv = __hip_atomic_load(part + (qm * 8 + r2) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const int r = 2 * r2, ch = (r & 3) + 8 * (r >> 2) + 4 * hl;      // r even: r + 1 is the next channel
+                                stg[ch * 32 + nl] += __uint_as_float((unsigned int)pv);
+                                stg[(ch + 1) * 32 + nl] += __uint_as_float((unsigned int)(pv >> 32));
+                            }
                         }
                         __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
@@ -604,7 +718,13 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
                     __builtin_amdgcn_wave_barrier();
                 }
             }
-            if constexpr (!F16) { if (next_stage) init_acc(k + 1); }
+            if constexpr (!F16) {
+                if (next_stage) {
+                    SegCur fc = cc;
+                    seg_next(fc);
+                    init_acc(fc.unit);
+                }
+            }
         }
         if constexpr (F16) { if (next_stage) note_max(); }   // waits for the tile loads issued at tap 0
         CT_PHASE(3);                       // epilogue
@@ -613,7 +733,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
         if constexpr (F16) {
             if (next_stage) {
                 const int et = tile_exp();
-                e_stage = (chunk + 1 == n_chunks) ? et : min(e_stage, et);     // a new output tile starts its own running scale
+                e_stage = seg_last ? et : min(e_stage, et);                    // a new output tile (or piece) starts its own running scale
                 store_tile(sp16_pow2i(e_stage));
             }
         } else {
@@ -629,8 +749,14 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
 #endif
 }
 
+// stream-K scratch: flags (one 32-bit word per workgroup, 4 KiB reserved), then one partial tile (256 threads x 64 floats) per workgroup
+constexpr size_t kSkFlagBytes = 4096;
+constexpr size_t kSkSlotBytes = 256 * 64 * sizeof(float);
+constexpr size_t kSkBytes = kSkFlagBytes + (size_t)2 * kSpCUs * kSkSlotBytes;
+
 template <int KH, int KW, bool GEN, bool F16 = false>
-static int launch_split(const ConvArgs &a, int N, hipStream_t s) {
+static int launch_split(const ConvArgs &a_in, int N, hipStream_t s) {
+    ConvArgs a = a_in;
     constexpr int ROWS = kSpTH + KH - 1, TWP = (KW > 1) ? kSpTW + 8 : kSpTW, NP = F16 ? 2 : 3;
     const size_t lds = (size_t)NP * ROWS * 2 * TWP * 16 + (size_t)(F16 ? 8 : 4) * NP * 2 * 64 * 16 + (size_t)4 * 32 * 32 * sizeof(float) + 16;
     const int tiles_x = (a.W + kSpTW - 1) / kSpTW, tiles_y = (a.H + kSpTH - 1) / kSpTH;
@@ -638,6 +764,14 @@ static int launch_split(const ConvArgs &a, int N, hipStream_t s) {
     if (n_tiles > 0x7fffffffLL) return CT_E_BADARG;
     static const int wgs_per_cu = [] { const char *e = getenv("CT_HIP_SPLIT_WGS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 2; }();
     const int grid = n_tiles < wgs_per_cu * kSpCUs ? (int)n_tiles : wgs_per_cu * kSpCUs;
+    // stream-K only where whole units quantise badly: more units than resident workgroups and a last round that is mostly idle
+    static const bool sk_on = [] { const char *e = getenv("CT_HIP_SPLIT_SK"); return !(e && atoi(e) == 0); }();
+    const double rounds = (double)n_tiles / (double)grid;
+    if (!(F16 && sk_on && a.sk_ws && a.rows_channels == 0 && wgs_per_cu == 2 && grid == 2 * kSpCUs && n_tiles > grid &&
+          (double)((n_tiles + grid - 1) / grid) > 1.08 * rounds)) {
+        a.sk_ws = nullptr;
+        a.sk_flags = nullptr;
+    }
     hipLaunchKernelGGL((conv_split_kernel<KH, KW, GEN, F16>), dim3(grid), dim3(256), lds, s, a, tiles_x, tiles_y, (int)n_tiles);
     CT_CHECK_LAUNCH();
     return CT_OK;
@@ -681,15 +815,19 @@ int conv_split(const ConvArgs &a, int N, int kh, int kw, bool gen, hipStream_t s
 
 extern "C" {
 
+size_t ct_conv_split_scratch_bytes(void) { return ct::kSkBytes; }
+
 int ct_conv2d_split_f32(const float *in, const float *in2, int cin1, const float *in3, int cin2, const void *wp_split, const float *bias,
                         const float *residual, float *out, int n, int cin, int cout, int h, int w, int kh, int kw, long long in_bstride,
                         long long in2_bstride, long long in3_bstride, long long out_bstride, long long res_bstride, int act, int clamp,
-                        int res_pre_act, int f16, int w_exp, int post_op, const float *p1, const float *p2, void *stream) {
+                        int res_pre_act, int f16, int w_exp, int post_op, const float *p1, const float *p2, void *scratch,
+                        long long scratch_bytes, void *stream) {
     if (!in || !wp_split || !bias || !out || n < 0 || cin < 1 || cout < 1 || h < 0 || w < 0 || act < 0 || act > 5) return CT_E_BADARG;
     if (post_op < 0 || post_op > 2 || (post_op && (!f16 || !p1 || (post_op == 2 && !p2)))) return CT_E_BADARG;
     if (post_op && ((reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15)) return CT_E_ALIGN;
     if (in2 && (cin1 < 16 || cin1 >= cin || (cin1 % 16))) return CT_E_BADARG;
     if (in3 && (!in2 || cin2 <= cin1 || cin2 >= cin || (cin2 % 16))) return CT_E_BADARG;
+    if (scratch && ((reinterpret_cast<uintptr_t>(scratch) & 15) || scratch_bytes < (long long)ct::kSkBytes)) return CT_E_WORKSPACE;
     if (n == 0 || h == 0 || w == 0) return CT_OK;
     ct::ConvArgs a;
     a.in = in; a.in2 = in2; a.cin1 = in2 ? cin1 : cin; a.in2_bstride = in2_bstride;
@@ -701,6 +839,10 @@ int ct_conv2d_split_f32(const float *in, const float *in2, int cin1, const float
     a.res_pre = (residual && res_pre_act) ? 1 : 0;
     a.f16 = f16 ? 1 : 0; a.w_exp = f16 ? w_exp : 0;
     a.post_op = post_op; a.p1 = p1; a.p2 = p2;
+    if (scratch && f16) {
+        a.sk_flags = reinterpret_cast<unsigned int *>(scratch);
+        a.sk_ws = reinterpret_cast<float *>(reinterpret_cast<char *>(scratch) + ct::kSkFlagBytes);
+    }
     const int rc = ct::conv_split(a, n, kh, kw, true, (hipStream_t)stream);
     return rc == 1 ? CT_E_BADARG : rc;
 }

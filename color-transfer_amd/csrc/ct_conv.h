@@ -31,6 +31,8 @@ struct ConvArgs {
     const float *p2 = nullptr;
     int res_pre = 0;            // split kernel only: 1 = `residual` is added BEFORE the activation (a pre-computed partial convolution)
     int rows_c0 = 0;            // channels rows_c0 .. rows_c0 + cout (multiples of 4); no residual / clamp in this mode
+    float *sk_ws = nullptr;         // split kernel, F16 form: stream-K scratch (partial tiles, one 64 KiB slot per workgroup), or NULL
+    unsigned int *sk_flags = nullptr;   // ... and its flags (one per workgroup; zero between launches)
 };
 
 struct GConvArgs {

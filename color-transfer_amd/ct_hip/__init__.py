@@ -18,7 +18,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CT_HIP_LIB") or os.path.join(_HERE, "libct_hip.so")   # CT_HIP_LIB: tuning builds only
 
-CT_ABI_VERSION = 5            # include/ct_hip.h: CT_ABI_VERSION; lib() refuses any other library
+CT_ABI_VERSION = 6            # include/ct_hip.h: CT_ABI_VERSION; lib() refuses any other library
 CT_LAB_STATS_STRIDE = 8
 CT_RGB_STATS_STRIDE = 16
 CT_WS_LAB_STATS, CT_WS_RGB_MEANCOV, CT_WS_REINHARD, CT_WS_IDT, CT_WS_REINHARD_PSNR, CT_WS_REINHARD_PERSIST = 0, 1, 2, 3, 4, 5
@@ -598,7 +598,8 @@ SIGNATURES.update({
     "ct_pam_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
     "ct_conv2d_split_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int,
                                      _c_int, _c_int, _c_ll, _c_ll, _c_ll, _c_ll, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p,
-                                     _c_p, _c_p]),
+                                     _c_p, _c_p, _c_ll, _c_p]),
+    "ct_conv_split_scratch_bytes": (_c_sz, []),
     "ct_pam_attend_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "ct_pam_valid_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_sz, _c_p]),
 })
@@ -698,6 +699,41 @@ def _split_ok(x, out, residual, kh, kw, stride, ph, pw):
     return True
 
 
+_sk_cache = {}                                   # (device index, stream) -> zero-initialised stream-K scratch of ct_conv2d_split_f32
+_stream_k = True
+
+
+def set_conv_stream_k(on):
+    """False: the tile convolution gets no scratch, i.e. every workgroup computes whole (tile, 64-channel) units (include/ct_hip.h:
+    ct_conv2d_split_f32, scratch == NULL); True (default): badly quantised launches share units between neighbouring workgroups."""
+    global _stream_k
+    _stream_k = bool(on)
+
+
+def conv_stream_k_state(device=None):
+    """(nonzero flag words, consumers that gave up) of the current stream's stream-K scratch -- both 0 between launches; None
+    before the first launch on this stream."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    buf = _sk_cache.get((device.index, torch.cuda.current_stream(device).cuda_stream))
+    if buf is None:
+        return None
+    words = buf[:4096].view(torch.int32)
+    return int(words[:1000].ne(0).sum()), int(words[1000])
+
+
+def _conv_scratch(device):
+    """The stream-K scratch of the tile convolution for the current stream (include/ct_hip.h: all zero before its first use, then
+    owned by the launches of one stream, which leave its flag words zero again)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    need = lib().ct_conv_split_scratch_bytes()
+    with _lock:
+        buf = _sk_cache.get(key)
+        if buf is None:
+            buf = torch.zeros(need, dtype=torch.uint8, device=device)
+            _sk_cache[key] = buf
+    return buf
+
+
 def _conv_split(x, split, cout, kh, kw, act, residual, clamp, out, x2=None, x3=None, res_pre=False, post=None):
     ws, b64 = split[0], split[1]
     f16, w_exp = 0, 0
@@ -715,10 +751,12 @@ def _conv_split(x, split, cout, kh, kw, act, residual, clamp, out, x2=None, x3=N
         check(lib().ct_conv3x3_ws16_f32(_ptr(x), _ptr(w16), int(w_exp), _ptr(b64), _opt(residual), _ptr(out), n, cin, cout, h, w,
                                         _nchw_bstride(x), _nchw_bstride(out), rs, int(act), int(bool(clamp)), _stream()))
         return out
+    scratch = _conv_scratch(x.device) if (f16 and _stream_k) else None
     check(lib().ct_conv2d_split_f32(_ptr(x), _opt(x2), cin1, _opt(x3), cin2, _ptr(ws), _ptr(b64), _opt(residual), _ptr(out), n, cin,
                                     cout, h, w, kh, kw, _nchw_bstride(x), _nchw_bstride(x2) if x2 is not None else 0,
                                     _nchw_bstride(x3) if x3 is not None else 0, _nchw_bstride(out), rs, int(act), int(bool(clamp)),
-                                    int(bool(res_pre)), f16, int(w_exp), int(post_op), _opt(p1), _opt(p2), _stream()))
+                                    int(bool(res_pre)), f16, int(w_exp), int(post_op), _opt(p1), _opt(p2), _opt(scratch),
+                                    scratch.numel() if scratch is not None else 0, _stream()))
     return out
 
 

@@ -34,9 +34,9 @@ extern "C" {
 #define CT_E_ALIGN (-3)      /* image base not aligned to its element size */
 
 /* bumped whenever an entry point changes its argument list (2: ct_attention_tokens_f32 gained kv_shift; 3: round 3; 4: ct_conv2d_split_rows_f32, res_pre_act, ct_linear_ws16_f32, layernorm partials, f16 form of ct_conv2d_split*;
- * 5: ct_reinhard_persist_*, ct_reinhard_psnr_u8, CT_WS_REINHARD_PERSIST);
+ * 5: ct_reinhard_persist_*, ct_reinhard_psnr_u8, CT_WS_REINHARD_PERSIST; 6: ct_conv2d_split_f32 gained scratch / scratch_bytes);
  * the ctypes binding refuses a library whose ct_abi_version() differs */
-#define CT_ABI_VERSION 5
+#define CT_ABI_VERSION 6
 
 /* doubles per image in a stats record written by ct_lab_stats / ct_rgb_meancov */
 #define CT_LAB_STATS_STRIDE 8  /* mean[3], std[3] (population, ddof 0), n, 0           */
@@ -278,12 +278,19 @@ int ct_conv2d_f32(const float *in, const float *wp, const float *bias, const flo
  * post_op (f16 form only; p1 / p2 dense tensors with out's strides): 1 = the activated result times p1 (the GRU's r * h,
  * reg_refine.py:50), 2 = (1 - p1) * p2 + p1 * result (its gate h = (1 - z) h + z q, reg_refine.py:47,55), before the clamp.
  * residual: added after the activation (ResB skip), or -- res_pre_act != 0 -- BEFORE it: a pre-computed partial convolution
- * (the SepConvGRU's loop-invariant `inp` channels, reg_refine.py:25-55: conv(cat([h, inp, motion])) = conv_inp(inp) + conv(rest)). */
+ * (the SepConvGRU's loop-invariant `inp` channels, reg_refine.py:25-55: conv(cat([h, inp, motion])) = conv_inp(inp) + conv(rest)).
+ * scratch (nullable; f16 form; 16-byte aligned, >= ct_conv_split_scratch_bytes(), ALL ZERO before its first use, then owned by
+ * the launches of ONE stream: each launch leaves its flag words zero again): lets a launch whose (8x32-pixel, 64-channel) units
+ * do not fill a whole number of rounds of the 512 resident workgroups share the units' input-channel loops between neighbouring
+ * workgroups (stream-K: e.g. 544 units take 1.06 rounds instead of 2).  The float32 sums of a shared unit are added in a fixed
+ * order, so results are deterministic; they differ from the scratch == NULL result by float32 rounding only.
+ * CT_E_WORKSPACE: scratch misaligned or too small. */
+size_t ct_conv_split_scratch_bytes(void);
 int ct_conv2d_split_f32(const float *in, const float *in2, int cin1, const float *in3, int cin2, const void *wp_split,
                         const float *bias, const float *residual, float *out, int n, int cin, int cout, int h, int w, int kh,
                         int kw, long long in_bstride, long long in2_bstride, long long in3_bstride, long long out_bstride,
                         long long res_bstride, int act, int clamp, int res_pre_act, int f16, int w_exp, int post_op,
-                        const float *p1, const float *p2, void *stream);
+                        const float *p1, const float *p2, void *scratch, long long scratch_bytes, void *stream);
 
 /* ct_conv2d_split_f32 of one input tensor with the result stored as TOKEN ROWS: out_rows[(n*h + y)*w + x][rows_c0 + co] of a
  * [n*h, w, rows_channels] tensor (rows_channels, rows_c0, cout multiples of 4; rows_c0 + cout <= rows_channels).  The query / key /

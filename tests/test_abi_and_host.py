@@ -30,8 +30,8 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "library does not export %s" % name
     # the ctypes signature table binds exactly the declared entry points
     assert sorted(ct_hip.SIGNATURES.keys()) == declared
-    assert ct_hip.lib().ct_abi_version() == ct_hip.CT_ABI_VERSION == 5
-    assert re.search(r"#define CT_ABI_VERSION 5\b", open(HEADER).read())
+    assert ct_hip.lib().ct_abi_version() == ct_hip.CT_ABI_VERSION == 6
+    assert re.search(r"#define CT_ABI_VERSION 6\b", open(HEADER).read())
     assert ct_hip.lib().ct_error_string(-2).decode().startswith("workspace")
     assert ct_hip.lib().ct_workspace_bytes(ct_hip.CT_WS_REINHARD, 1920 * 1080, 4) > 0
     assert ct_hip.lib().ct_idt_workspace_bytes(1, 4, 255) > 0
@@ -223,3 +223,24 @@ def test_persistent_reinhard_entries_reject_bad_arguments_without_a_gpu():
         assert fn(null, null, null, null, null, -1, 1, null, null, 0, null) == -1
     assert lib.ct_fft2d_c2c_f32(null, 4, 4, 1, 0, null) == -1
     assert lib.ct_set_lab_mode_thread(7) == -1 and lib.ct_set_lab_mode_thread(-1) == 0
+
+
+def test_conv_scratch_argument_checks_without_a_gpu():
+    """ct_conv2d_split_f32 checks its stream-K scratch (alignment, size) before anything touches the device"""
+    import ctypes
+    import ct_hip
+    lib = ct_hip.lib()
+    need = lib.ct_conv_split_scratch_bytes()
+    assert need >= 4096 + 512 * 256 * 64 * 4 and need % 16 == 0
+    host = (ctypes.c_char * 256)()
+    p = ctypes.cast(host, ctypes.c_void_p)
+    addr = p.value
+
+    def call(scratch, nbytes, n=0):
+        return lib.ct_conv2d_split_f32(p, None, 0, None, 0, p, p, None, p, n, 16, 64, 8, 32, 3, 3, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, None, None,
+                                       scratch, nbytes, None)
+    aligned = ctypes.c_void_p((addr + 15) & ~15)
+    assert call(None, 0) == 0                                           # an empty batch, no scratch: a no-op
+    assert call(aligned, need) == 0                                     # ... with a well-formed scratch too
+    assert call(aligned, need - 1) == -2                                # CT_E_WORKSPACE: too small
+    assert call(ctypes.c_void_p(aligned.value + 4), need) == -2         # misaligned

@@ -245,3 +245,78 @@ def test_conv_post_ops_equal_the_elementwise_kernels(hip):
     assert (hn.double().cpu() - ref).abs().max().item() < 3e-6
     with pytest.raises(hip.CtHipError):
         hip.gconv2d(xc, wp, bp, cout, (1, 5), 1, (0, 2), act=4, addend=ac, post=(2, zc, hc[:, :64]))
+
+
+SK_CASES = [   # (cin, cout, kh, kw, h, w): (tile, 64-channel) units / 512 resident workgroups -> rounds the whole-unit form would take
+    (256, 128, 1, 5, 136, 240),    # 544 units: 1.06 rounds (the SepConvGRU at a 544 x 960 inference size)
+    (160, 128, 5, 1, 136, 240),    # ... with 10 chunks per unit: shares of 10.6 stages
+    (128, 96, 3, 3, 136, 240),     # 544 units, the second group half empty
+    (64, 192, 3, 3, 136, 240),     # 816 units, three groups per tile
+    (48, 64, 1, 1, 200, 328),      # 550 units of three stages each
+    (32, 64, 3, 3, 264, 448),      # 924 units of two stages: a share is 3.6 stages (whole units between the two pieces)
+]
+
+
+@pytest.mark.parametrize("cfg", SK_CASES)
+def test_conv_split_stream_k(hip, cfg):
+    """launches whose units do not fill whole rounds of the resident workgroups share the units' channel loops between neighbouring
+    workgroups (csrc/conv_split.hip, stream-K): the whole-unit form's result within the kernel's bound (the pieces of a shared unit carry their own fp16
+    scales and meet in one float32 addition), against float64 within the same bound, repeatable bit for bit, flag words zero afterwards -- plain, with a second
+    input tensor, with a pre-activation addend + activation + GRU post-op, and with a skip tensor"""
+    cin, cout, kh, kw, h, w = cfg
+    n = 2
+    x, wt, b = rnd(n, cin, h, w), rnd(cout, cin, kh, kw) / (cin * kh * kw) ** 0.5, rnd(cout)
+    x[:, : cin // 2] *= 50.0                 # the head piece of a split unit lives at another scale than its tail
+    add, hid, res = rnd(n, cout, h, w), rnd(n, cout, h, w), rnd(n, cout, h, w)
+    wp, bp = hip.pack_gconv_weight(wt.cuda(), b.cuda())
+    pad = (kh // 2, kw // 2)
+    xc, ac, hc, rc = x.cuda(), add.cuda(), hid.cuda(), res.cuda()
+    lin = F.conv2d(x.double(), wt.double(), b.double(), padding=pad)
+    bound = F.conv2d(x.double().abs(), wt.double().abs(), None, padding=pad)
+
+    def run():
+        outs = [hip.gconv2d(xc, wp, bp, cout, (kh, kw), 1, pad)]
+        if cin % 32 == 0:
+            outs.append(hip.gconv2d(xc[:, : cin // 2].contiguous(), wp, bp, cout, (kh, kw), 1, pad, x2=xc[:, cin // 2:].contiguous()))
+        outs.append(hip.gconv2d(xc, wp, bp, cout, (kh, kw), 1, pad, act=3, addend=ac, post=(1, hc, None)))
+        outs.append(hip.gconv2d(xc, wp, bp, cout, (kh, kw), 1, pad, residual=rc))
+        return outs
+    hip.set_conv_stream_k(False)
+    try:
+        whole = run()
+    finally:
+        hip.set_conv_stream_k(True)
+    shared, again = run(), run()
+    assert hip.conv_stream_k_state() == (0, 0)
+    refs = [lin] + ([lin] if cin % 32 == 0 else []) + [torch.sigmoid(lin + add.double()) * hid.double(), lin + res.double()]
+    assert any(not torch.equal(a_, b_) for a_, b_ in zip(shared, whole))          # the launch did take the shared form
+    for got, rep, ref_whole, ref in zip(shared, again, whole, refs):
+        assert torch.equal(got, rep)
+        # both forms are within the kernel's bound of the truth; the tail piece of a shared unit even runs at its own (finer) scale
+        assert ((got.double() - ref_whole.double()).cpu().abs() / (1.5e-6 * bound + 2e-6)).max().item() < 1.0
+        assert ((got.double().cpu() - ref).abs() / (1.5e-6 * bound + 2e-6)).max().item() < 1.0
+
+
+def test_conv_split_stream_k_many_launches_one_scratch(hip):
+    """the scratch is owned by the stream: launches of different shapes back to back (each leaves the flag words zero), and a
+    second stream gets a scratch of its own"""
+    shapes = [(128, 128, 1, 5, 136, 240), (64, 192, 3, 3, 136, 240), (128, 128, 5, 1, 136, 240)]
+    data = []
+    for cin, cout, kh, kw, h, w in shapes:
+        x, wt, b = rnd(2, cin, h, w).cuda(), (rnd(cout, cin, kh, kw) / (cin * kh * kw) ** 0.5).cuda(), rnd(cout).cuda()
+        data.append((x, hip.pack_gconv_weight(wt, b), cout, (kh, kw), (kh // 2, kw // 2)))
+    first = [hip.gconv2d(x, p[0], p[1], co, k, 1, pd) for x, p, co, k, pd in data]
+    for _ in range(3):
+        for (x, p, co, k, pd), ref in zip(data, first):
+            assert torch.equal(hip.gconv2d(x, p[0], p[1], co, k, 1, pd), ref)
+    assert hip.conv_stream_k_state() == (0, 0)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        other = [hip.gconv2d(x, p[0], p[1], co, k, 1, pd) for x, p, co, k, pd in data]
+        side.synchronize()
+        assert hip.conv_stream_k_state() == (0, 0)
+    side.synchronize()
+    for a_, b_ in zip(other, first):
+        assert torch.equal(a_, b_)
+    assert len(hip._sk_cache) >= 2
