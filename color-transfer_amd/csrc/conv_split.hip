@@ -797,6 +797,7 @@ int conv_split(const ConvArgs &a, int N, int kh, int kw, bool gen, hipStream_t s
         if (kh == 1 && kw == 1) return launch_split<1, 1, true, true>(a, N, s);
         if (kh == 1 && kw == 5) return launch_split<1, 5, true, true>(a, N, s);
         if (kh == 5 && kw == 1) return launch_split<5, 1, true, true>(a, N, s);
+        if (kh == 2 && kw == 2) return launch_split<2, 2, true, true>(a, N, s);     // taps at offsets -1 / 0: a stride-2 3x3 after space-to-depth
         return 1;
     }
     if (gen) {

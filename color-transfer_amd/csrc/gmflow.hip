@@ -190,6 +190,29 @@ __global__ __launch_bounds__(256) void inorm_apply_kernel(const float *__restric
 //   op 3: y = (a / 255 - mean[c]) / std[c]   (normalize_img, utils.py:26-34; a: [N,3,H,W], plane given)
 //   op 4: y = a * s0             op 5: tanh(a) for channels < split, relu(a) otherwise (refine_proj chunk, unimatch.py:320-323)
 // =================================================================================================
+// Space-to-depth by 2: out[n][(2 sy + sx) C + c][y][x] = in[n][c][2y + sy][2x + sx] (sub-position major, so the (0, 0) sub-grid --
+// what a stride-2 1x1 convolution reads -- is the first C channels).  A stride-2 3x3 "same" convolution is a stride-1 2x2
+// convolution over this tensor (block offsets -1 / 0; the (by, sy) pairs (0,1), (1,0), (1,1) are the rows ky = 0, 1, 2 and (0,0)
+// carries zero weights), which the MFMA tile kernel computes (conv_split_kernel<2, 2>): backbone.py:14-17,53,67 and the
+// stride-2 trident branch (trident_conv.py:64-72) leave the generic kernel.  One thread: 8 input columns -> 4 + 4 outputs.
+__global__ __launch_bounds__(256) void space_to_depth2_kernel(const float *__restrict__ in, float *__restrict__ out, int C, int H, int W,
+                                                              long long in_bstride, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;          // over [n][c][input row][W / 8]
+    if (i >= total) return;
+    const int w8 = W >> 3, ho = H >> 1, wo = W >> 1;
+    const int xg = (int)(i % w8);
+    long long r = i / w8;
+    const int yin = (int)(r % H); r /= H;
+    const int c = (int)(r % C);
+    const long long n = r / C;
+    const float *src = in + n * in_bstride + ((size_t)c * H + yin) * W + 8 * xg;
+    const float4 a = *reinterpret_cast<const float4 *>(src), b = *reinterpret_cast<const float4 *>(src + 4);
+    const int sy = yin & 1, y = yin >> 1;
+    float *dst = out + ((size_t)(n * 4 + 2 * sy) * C + c) * ho * wo + (size_t)y * wo + 4 * xg;
+    *reinterpret_cast<float4 *>(dst) = make_float4(a.x, a.z, b.x, b.z);                       // sx = 0
+    *reinterpret_cast<float4 *>(dst + (size_t)C * ho * wo) = make_float4(a.y, a.w, b.y, b.w);   // sx = 1
+}
+
 __global__ void eltwise_kernel(const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ c,
                                float *__restrict__ y, long long n, int op, int plane, int chans, int split, float s0) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1707,6 +1730,18 @@ int ct_instance_norm_f32(const float *x, const float *skip, float *y, int planes
         return CT_OK;
     }
     hipLaunchKernelGGL(ct::inorm_kernel, dim3(planes), dim3(256), 0, (hipStream_t)stream, x, skip, y, plane, eps, mode);
+    CT_CHECK_LAUNCH();
+    return CT_OK;
+}
+
+int ct_space_to_depth2_f32(const float *in, float *out, int n, int c, int h, int w, long long in_bstride, void *stream) {
+    if (!in || !out || n < 0 || c < 1 || h < 2 || w < 8 || (h & 1) || (w & 7) || (in_bstride & 3)) return CT_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) return CT_E_ALIGN;
+    if (n == 0) return CT_OK;
+    const long long total = (long long)n * c * h * (w >> 3);
+    if ((total + 255) / 256 > 0x7fffffffLL) return CT_E_BADARG;
+    hipLaunchKernelGGL(ct::space_to_depth2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, c, h, w,
+                       in_bstride, total);
     CT_CHECK_LAUNCH();
     return CT_OK;
 }

@@ -11,6 +11,7 @@ GPU raises.
 import ctypes
 import os
 import threading
+import weakref
 import numpy as np
 
 import torch
@@ -684,7 +685,7 @@ def _ws16_ok(x, split, kh, kw):
 def _split_operands(weight, bias):
     """(bf16 pieces, padded bias, fp16 image or None): what travels with a packed convolution weight as `_ct_split`"""
     cout, cin, kh, kw = weight.shape
-    w16 = pack_conv_weight_split16(weight) if (kh, kw) in ((3, 3), (1, 1), (1, 5), (5, 1)) else None
+    w16 = pack_conv_weight_split16(weight) if (kh, kw) in ((3, 3), (1, 1), (1, 5), (5, 1), (2, 2)) else None
     return pack_conv_weight_split(weight, bias) + (w16,)
 
 
@@ -885,6 +886,7 @@ SIGNATURES.update({
     "ct_instance_norm_workspace_bytes": (ctypes.c_size_t, [_c_int]),
     "ct_instance_norm_f32": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_f, _c_int, _c_p, ctypes.c_size_t, _c_p]),
     "ct_eltwise_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_f, _c_p]),
+    "ct_space_to_depth2_f32": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_ll, _c_p]),
     "ct_linear_tokens_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p, ctypes.c_longlong, _c_int, _c_int, _c_int, _c_p]),
     "ct_linear_tokens_split_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p, ctypes.c_longlong, _c_int, _c_int, _c_int, _c_p]),
     "ct_layernorm128_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_p]),
@@ -937,7 +939,47 @@ def pack_gconv_weight(weight, bias):
         b[:cout] = bias.detach().float()
     if kh * kw <= 9:
         wp._ct_split = _split_operands(weight, bias)
+    if (kh, kw) == (3, 3):
+        wp._ct_src = (weight, bias)               # a stride-2 use builds its space-to-depth form from these (first use, cached)
     return wp, b
+
+
+_s2d_last = [None, None]                          # (key, tensor): the two stride-2 convolutions of a residual block read one input
+
+
+def space_to_depth2(x):
+    """[n, c, h, w] -> [n, 4c, h/2, w/2], channel (2 sy + sx) c + ch = x[:, ch, sy::2, sx::2] (ct_space_to_depth2_f32)"""
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4 or not x[0].is_contiguous():
+        raise CtHipError("space_to_depth2 needs a float32 CUDA tensor [n, c, h, w] with dense images (no CPU path)")
+    _check_device(x)
+    n, c, h, w = x.shape
+    # the SAME tensor object, unchanged, on the same stream (an address can be reused by another tensor: identity, not data_ptr)
+    hit = _s2d_last[0]
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    if hit is not None and hit[0]() is x and hit[1] == (x._version, stream):
+        return _s2d_last[1]
+    out = torch.empty((n, 4 * c, h // 2, w // 2), dtype=torch.float32, device=x.device)
+    check(lib().ct_space_to_depth2_f32(_ptr(x), _ptr(out), n, c, h, w, _nchw_bstride(x), _stream()))
+    _s2d_last[0], _s2d_last[1] = (weakref.ref(x), (x._version, stream)), out
+    return out
+
+
+def _split_s2d(wp):
+    """the 2x2 / 4c form of a 3x3 stride-2 convolution's weight (include/ct_hip.h: ct_space_to_depth2_f32), packed like _ct_split"""
+    hit = getattr(wp, "_ct_split_s2d", None)
+    weight, bias = wp._ct_src
+    ver = (weight._version, weight.data_ptr(), None if bias is None else (bias._version, bias.data_ptr()))
+    if hit is None or hit[0] != ver:
+        cout, cin = weight.shape[:2]
+        w2 = torch.zeros((cout, 4, cin, 2, 2), dtype=torch.float32, device=weight.device)
+        wd = weight.detach().float()
+        taps = {0: (0, 1), 1: (1, 0), 2: (1, 1)}           # k -> (block offset index, sub-position): 2 o + k - 1 = 2 (o + b - 1) + s
+        for ky, (by, sy) in taps.items():
+            for kx, (bx, sx) in taps.items():
+                w2[:, 2 * sy + sx, :, by, bx] = wd[:, :, ky, kx]
+        hit = (ver, _split_operands(w2.reshape(cout, 4 * cin, 2, 2), bias))
+        wp._ct_split_s2d = hit
+    return hit[1]
 
 
 def gconv2d(x, wp, bias, cout, ksize, stride=1, padding=0, act=ACT_NONE, out=None, x2=None, residual=None, addend=None, post=None):
@@ -980,6 +1022,15 @@ def gconv2d(x, wp, bias, cout, ksize, stride=1, padding=0, act=ACT_NONE, out=Non
     if out is None:
         out = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device)
     split = getattr(wp, "_ct_split", None)
+    # stride 2, 3x3 "same" or 1x1: the MFMA tile kernel over the space-to-depth image of x (fp16 form)
+    if (stride == 2 and _conv_mode == "split" and _ws16 and split is not None and bias is not None and residual is None and cout > 4 and
+            h % 2 == 0 and w % 8 == 0 and x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0 and x[0].is_contiguous() and
+            out.data_ptr() % 16 == 0 and out.stride(0) % 4 == 0 and
+            (((kh, kw, ph, pw) == (3, 3, 1, 1) and hasattr(wp, "_ct_src")) or (kh, kw, ph, pw) == (1, 1, 0, 0))):
+        s2d = space_to_depth2(x)
+        if kh == 1:
+            return _conv_split(s2d[:, :cin], split, cout, 1, 1, act, None, False, out)
+        return _conv_split(s2d, _split_s2d(wp), cout, 2, 2, act, None, False, out)
     # cout <= 4 (the flow head's 256 -> 2): ct_gconv2d_f32's direct kernel instead of a 64-output-channel tile
     if split is not None and bias is not None and (cout > 4 or residual is not None) and _split_ok(x, out, residual, kh, kw, stride, ph, pw):
         return _conv_split(x, split, cout, kh, kw, act, residual, False, out)

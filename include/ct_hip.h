@@ -263,7 +263,8 @@ int ct_conv2d_f32(const float *in, const float *wp, const float *bias, const flo
 /* The same convolution family on the bf16 matrix pipe with float32-grade accuracy (csrc/conv_split.hip): every float32
  * operand is split into three bf16 pieces and a product is the sum of the six partial products above 2^-16 of the
  * leading one, accumulated in float32 (error ~ one float32 rounding per product; NOT bitwise the fmaf chain of
- * ct_conv2d_f32).  Stride 1, padding k/2, kernel (kh,kw) in {3x3, 1x1, 1x5, 5x1}; w % 4 == 0; in / out / residual
+ * ct_conv2d_f32).  Stride 1, padding k/2, kernel (kh,kw) in {3x3, 1x1, 1x5, 5x1} (f16 form also 2x2 with padding 1 on the top / left
+ * only: see ct_space_to_depth2_f32); w % 4 == 0; in / out / residual
  * 16-byte aligned with batch strides % 4 == 0 (CT_E_BADARG otherwise: use ct_conv2d_f32 / ct_gconv2d_f32 then).
  * wp_split: bf16 bit patterns [ceil(cout/64)][ceil(cin/16)][kh*kw][piece hi,mid,lo][m][k-half][cout%32][8 channels];
  * bias: zero padded to 64*ceil(cout/64).  act: 0 none, 1 LeakyReLU(0.01), 2 ReLU, 3 sigmoid, 4 tanh, 5 swish.
@@ -343,6 +344,11 @@ int ct_gconv2d_f32(const float *in, const float *wp, const float *bias, float *o
 size_t ct_instance_norm_workspace_bytes(int planes);
 int ct_instance_norm_f32(const float *x, const float *skip, float *y, int planes, int plane, float eps,
                          int mode, void *ws, size_t ws_bytes, void *stream);
+/* Space-to-depth by 2 of an NCHW tensor (h even, w % 8 == 0, 16-byte aligned): out[n][(2 sy + sx) c_total + c][y][x] =
+ * in[n][c][2y + sy][2x + sx], out dense [n][4c][h/2][w/2].  With it a stride-2 3x3 "same" convolution (unimatch/backbone.py:14-17,
+ * 53,67; trident_conv.py:64-72) is ct_conv2d_split_f32 with kh = kw = 2 (taps at block offsets -1 / 0, f16 form only) over 4c
+ * channels, and a stride-2 1x1 convolution is the 1x1 convolution of its first c channels. */
+int ct_space_to_depth2_f32(const float *in, float *out, int n, int c, int h, int w, long long in_bstride, void *stream);
 /* elementwise: op 0 a+b, 1 a*b, 2 (1-a)*b + a*c (GRU update, reg_refine.py:47,55), 3 normalize_img (utils.py:26-34),
  *   4 a*s0, 5 tanh on channels < split / relu on the rest (unimatch.py:320-323)                                   */
 int ct_eltwise_f32(const float *a, const float *b, const float *c, float *y, long long n, int op,

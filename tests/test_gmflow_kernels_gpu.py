@@ -38,7 +38,10 @@ def rnd(*shape):
     (3, 384, 128, 21, 68, 5, 1, 1, 2, 0), (2, 64, 192, 17, 100, 1, 1, 1, 0, 0),
     # the direct VALU kernels (csrc/conv_direct.hip): cout <= 4, and cin <= 3 with a 7x7 kernel; several tiles, ragged edges
     (2, 256, 2, 37, 70, 3, 3, 1, 1, 1), (1, 61, 3, 20, 45, 3, 3, 1, 1, 1), (1, 16, 4, 9, 33, 1, 1, 1, 0, 0),
-    (2, 2, 128, 40, 72, 7, 7, 1, 3, 3), (1, 3, 64, 64, 131, 7, 7, 2, 3, 3)])
+    (2, 2, 128, 40, 72, 7, 7, 1, 3, 3), (1, 3, 64, 64, 131, 7, 7, 2, 3, 3),
+    # stride 2 on the MFMA tile kernel through the space-to-depth image (even height, width % 8 == 0; split mode)
+    (2, 64, 96, 40, 72, 3, 3, 2, 1, 1), (2, 64, 96, 40, 72, 1, 1, 2, 0, 0), (1, 96, 128, 24, 64, 3, 3, 2, 1, 1),
+    (2, 128, 128, 16, 56, 3, 3, 2, 1, 1), (1, 40, 70, 18, 40, 3, 3, 2, 1, 1)])
 def test_gconv(hip, cfg, conv_mode):
     n, cin, cout, h, w, kh, kw, s, ph, pw = cfg
     x, wt, b = rnd(n, cin, h, w), rnd(cout, cin, kh, kw) / (cin * kh * kw) ** 0.5, rnd(cout)
@@ -464,3 +467,22 @@ def test_attention_tiny_sequences(hip, l):
     hip.check(lib.ct_attention_rows64_f32(qc.data_ptr(), kc.data_ptr(), None, None, stats.data_ptr(), b, l, 1.0 / 64, None))
     hip.check(lib.ct_attention_colsum64_f32(qc.data_ptr(), kc.data_ptr(), stats.data_ptr(), colsum.data_ptr(), b, l, 1.0 / 64, None))
     close(colsum, p6.sum(dim=1), "column sums", atol=5e-5, rtol=1e-4)
+
+
+def test_space_to_depth_and_stride2_cache(hip):
+    """ct_space_to_depth2_f32: channel (2 sy + sx) C + c of the result is x[:, c, sy::2, sx::2]; the binding keeps the image of the
+    last input (the two stride-2 convolutions of a residual block read the same tensor) and notices an in-place change"""
+    x = rnd(2, 5, 12, 24).cuda()
+    s2d = hip.space_to_depth2(x)
+    assert s2d.shape == (2, 20, 6, 12)
+    for sy in range(2):
+        for sx in range(2):
+            assert torch.equal(s2d[:, (2 * sy + sx) * 5:(2 * sy + sx + 1) * 5], x[:, :, sy::2, sx::2])
+    assert hip.space_to_depth2(x) is s2d
+    x.mul_(2.0)
+    again = hip.space_to_depth2(x)
+    assert again is not s2d and torch.equal(again[:, :5], x[:, :, ::2, ::2])
+    view = rnd(2, 8, 12, 24).cuda()[:, 2:7]                   # a channel slice: batch stride != c * h * w
+    assert torch.equal(hip.space_to_depth2(view)[:, 5:10], view[:, :, 0::2, 1::2])
+    with pytest.raises(hip.CtHipError):
+        hip.space_to_depth2(rnd(1, 4, 7, 24).cuda())
