@@ -475,6 +475,18 @@ def main():
             # the reference's algorithmic FLOPs per pair; 0.376e12 of them (the SepConvGRU's loop-invariant input blocks)
             # are convolved once per forward instead of once per refinement iteration, so this is a throughput equivalent
             extra["gmflow_960x540_tflops_f32_equivalent"] = 3.58357106688e12 * gr / 1e12
+            # the refinement correlation (6 launches per pair) is data dependent since round 4: a 4x8-pixel tile shares the box of
+            # its windows in LDS when the flow is smooth across the tile (what an optical flow is); the random-init model above emits
+            # noise of +-40 px, so every tile of the forward timed here takes the per-pixel form.  Both cases, on their own:
+            tk = torch.randn(2, 128 * 224, 128, device=device)
+            yy, xx = torch.meshgrid(torch.arange(128, dtype=torch.float32, device=device), torch.arange(224, dtype=torch.float32, device=device), indexing="ij")
+            smooth = torch.stack([0.05 * xx - 0.02 * yy, 0.03 * yy + 0.01 * xx], 0)[None].repeat(2, 1, 1, 1).contiguous()
+            noise = 40.0 * torch.randn(2, 2, 128, 224, device=device)
+            extra["gmflow_local_corr_flow_us"] = {
+                "smooth_flow_shared_box": forward_ms(lambda: ct_hip.local_corr_flow(tk, tk, smooth, 4))["median_ms"] * 1e3,
+                "noise_flow_40px_per_pixel_form": forward_ms(lambda: ct_hip.local_corr_flow(tk, tk, noise, 4))["median_ms"] * 1e3,
+                "note": "128x224 tokens, batch 2, radius 4; the forward above (random weights) runs the second case 6 times per pair"}
+            del tk, smooth, noise
             gmp = read_stamped(os.path.join(ROOT, "profiles", "r04_gmflow_960x540_mfma_pmc.json"))
             extra["gmflow_960x540_mfma_busy_time_weighted"] = gmp.get("_all_kernels", {}).get("mfma_busy_frac_time_weighted") if gmp else None
             if gmp:

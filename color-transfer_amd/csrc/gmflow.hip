@@ -1488,6 +1488,210 @@ __global__ __launch_bounds__(256) void local_corr_flow_kernel(const float *__res
     }
 }
 
+// The same correlation for a TILE of 4 x 8 pixels at once (round 4).  Neighbouring pixels of a smooth flow field sample almost the
+// same neighbourhood of feature1: the union of the tile's (2R+2)^2 windows, clipped to the image, is a box of P positions (13 x 17
+// = 221 for R = 4 and a constant flow) against 32 x 100 position reads of the per-pixel form.  The box is staged in LDS once per
+// 32-channel chunk (float32 as it is in memory: rows of 32 floats padded to 36, so that the MFMA operand reads are conflict-free
+// 16-byte reads), and D[position][pixel] = <f1[position], f0[pixel]> is ONE small GEMM, P x 32 x 128, on v_mfma_f32_32x32x2_f32:
+// exact float32 products, float32 accumulation, no operand conversion, no scales (a lane of k-half h takes channels 16 h + s of
+// the chunk at step s -- both operands alike, a dot product does not care about the order).  That pipe has 1/16 of the 16-bit
+// rate and is still 10x what this problem needs (57 k pixels x 221 x 128 MACs = 24 us chip-wide).  D goes back to LDS ([position]
+// [33]), and every (pixel, tap) combines its four integer-offset dots with the pixel's bilinear weights exactly as the per-pixel
+// form does (positions outside the image: zero, grid_sample's padding).  A tile whose box exceeds kLcMaxP positions (a flow
+// discontinuity inside the tile, NaN / huge flows) runs the per-pixel form, one wave per pixel, inside the same launch.
+constexpr int kLcTY = 4, kLcTX = 8, kLcTile = kLcTY * kLcTX, kLcMaxP = 320, kLcRow = 36, kLcChunk = 32;
+
+__device__ __forceinline__ void lcf_window(const float *__restrict__ flow, int b, size_t hw, long long pix, int x, int y, int H, int W,
+                                           int &x0, int &y0, float &wx1, float &wy1) {
+    const float cx = (W - 1) * 0.5f, cy = (H - 1) * 0.5f;
+    const float fx = flow[((size_t)b * 2 + 0) * hw + pix], fy = flow[((size_t)b * 2 + 1) * hw + pix];
+    // the reference normalises to [-1,1] and grid_sample maps back: ((g + 1) / 2) * (size - 1)
+    const float gx = (((float)x + fx) - cx) / cx, gy = (((float)y + fy) - cy) / cy;
+    const float px = ((gx + 1.0f) * 0.5f) * (float)(W - 1), py = ((gy + 1.0f) * 0.5f) * (float)(H - 1);
+    const float x0f = floorf(px), y0f = floorf(py);
+    wx1 = px - x0f; wy1 = py - y0f;
+    // far-out-of-range bases (NaN / inf flows included) are clamped so that the int arithmetic cannot overflow; every position
+    // is then outside the image and the row is all zeros, like grid_sample's
+    x0 = (x0f > -1e6f && x0f < 1e6f) ? (int)x0f : -1000000;
+    y0 = (y0f > -1e6f && y0f < 1e6f) ? (int)y0f : -1000000;
+}
+
+__global__ __launch_bounds__(256) void local_corr_flow_tile_kernel(const float *__restrict__ f0, const float *__restrict__ f1,
+                                                                   const float *__restrict__ flow, float *__restrict__ corr, int H,
+                                                                   int W, int R, float scale, int tiles_x) {
+    constexpr int C = 128;
+    __shared__ __attribute__((aligned(16))) float fa[kLcMaxP * kLcRow];      // the box's 32-channel chunk; later D [position][33]
+    __shared__ __attribute__((aligned(16))) float fb[kLcTile * kLcRow];      // the tile's pixels, same chunk
+    __shared__ int sx0[kLcTile], sy0[kLcTile], slive[kLcTile];
+    __shared__ float swx[kLcTile], swy[kLcTile];
+    __shared__ int sbox[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int ty0 = ((int)blockIdx.x / tiles_x) * kLcTY, tx0 = ((int)blockIdx.x % tiles_x) * kLcTX;
+    const int D = 2 * R + 1, NT = D * D, DP = D + 1;
+    const size_t hw = (size_t)H * W;
+    if (tid < kLcTile) {
+        const int y = ty0 + tid / kLcTX, x = tx0 + tid % kLcTX;
+        int x0 = 0, y0 = 0, live = 0;
+        float wx1 = 0.f, wy1 = 0.f;
+        if (y < H && x < W) {
+            lcf_window(flow, b, hw, (long long)y * W + x, x, y, H, W, x0, y0, wx1, wy1);
+            // live: the window [x0 - R, x0 + R + 1] x [y0 - R, y0 + R + 1] meets the image (otherwise the row is all zeros)
+            live = (x0 + R + 1 >= 0 && x0 - R < W && y0 + R + 1 >= 0 && y0 - R < H) ? 1 : 0;
+        }
+        sx0[tid] = x0; sy0[tid] = y0; swx[tid] = wx1; swy[tid] = wy1; slive[tid] = live;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = -0x7fffffff, by1 = -0x7fffffff;
+        for (int i = 0; i < kLcTile; ++i)
+            if (slive[i]) {
+                bx0 = min(bx0, sx0[i] - R); bx1 = max(bx1, sx0[i] + R + 1);
+                by0 = min(by0, sy0[i] - R); by1 = max(by1, sy0[i] + R + 1);
+            }
+        const bool some = bx1 >= bx0;                                         // a live pixel exists (its window meets the image)
+        sbox[0] = some ? max(bx0, 0) : 0; sbox[1] = some ? max(by0, 0) : 0;
+        sbox[2] = some ? min(bx1, W - 1) - max(bx0, 0) + 1 : 0;              // 0: nothing to stage, every output of the tile is zero
+        sbox[3] = some ? min(by1, H - 1) - max(by0, 0) + 1 : 0;
+    }
+    __syncthreads();
+    const int bx0 = sbox[0], by0 = sbox[1], BW = sbox[2], BH = sbox[3];
+    const bool any = BW > 0 && BH > 0;
+    const long long P64 = any ? (long long)BW * BH : 0;
+    if (P64 > kLcMaxP) {
+        // ---- per-pixel form for this tile: one wave per pixel, eight lanes per position (local_corr_flow_kernel) ----
+        float *a_s = fa + wave * 256, *d_s = a_s + 128, *o_s = fa + 1024;      // o_s [tap][33]: the tile's results, stored by plane below
+        for (int i = 0; i < kLcTile / 4; ++i) {
+            const int pl = wave * (kLcTile / 4) + i;
+            const int y = ty0 + pl / kLcTX, x = tx0 + pl % kLcTX;
+            if (y >= H || x >= W) continue;                                  // wave-uniform
+            const long long pix = (long long)y * W + x;
+            const int x0 = sx0[pl], y0 = sy0[pl];
+            const float wx1 = swx[pl], wy1 = swy[pl], wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+            *reinterpret_cast<float2 *>(&a_s[2 * lane]) = *reinterpret_cast<const float2 *>(f0 + ((size_t)b * hw + pix) * C + 2 * lane);
+            __builtin_amdgcn_wave_barrier();
+            const int ps = lane >> 3, oc = lane & 7, NPp = DP * DP;
+            float4 u[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) u[q] = *reinterpret_cast<const float4 *>(&a_s[16 * oc + 4 * q]);
+            for (int p0 = 0; p0 < NPp; p0 += 8) {
+                const int p = p0 + ps;
+                const int jj = p / DP, ii = p - jj * DP;
+                const int xx = x0 - R + ii, yy = y0 - R + jj;
+                float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+                if (p < NPp && xx >= 0 && xx < W && yy >= 0 && yy < H) {
+                    const float *bp = f1 + ((size_t)b * hw + (size_t)yy * W + xx) * C + 16 * oc;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 w4 = *reinterpret_cast<const float4 *>(bp + 4 * q);
+                        d0 = fmaf(u[q].x, w4.x, d0); d1 = fmaf(u[q].y, w4.y, d1); d2 = fmaf(u[q].z, w4.z, d2); d3 = fmaf(u[q].w, w4.w, d3);
+                    }
+                }
+                float d = (d0 + d1) + (d2 + d3);
+                d += __shfl_xor(d, 1, 64);
+                d += __shfl_xor(d, 2, 64);
+                d += __shfl_xor(d, 4, 64);
+                if (oc == 0 && p < NPp) d_s[p] = d;
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int t = lane; t < NT; t += 64) {
+                const int dy = t / D, dx = t - dy * D;
+                const float *dp = &d_s[dy * DP + dx];
+                const float v = (wx0 * wy0) * dp[0] + (wx1 * wy0) * dp[1] + (wx0 * wy1) * dp[DP] + (wx1 * wy1) * dp[DP + 1];
+                o_s[t * 33 + pl] = v * scale;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        for (int e = tid; e < NT * kLcTile; e += 256) {
+            const int t = e / kLcTile, pl = e - t * kLcTile;
+            const int y = ty0 + pl / kLcTX, x = tx0 + pl % kLcTX;
+            if (y < H && x < W) corr[((size_t)b * NT + t) * hw + (size_t)y * W + x] = o_s[t * 33 + pl];
+        }
+        return;
+    }
+    const int P = (int)P64, nblk = (P + 31) >> 5;
+    f32x16g acc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    const int m = lane & 31, kh = lane >> 5;
+    for (int c0 = 0; c0 < C && any; c0 += kLcChunk) {
+        // stage the chunk: 8 float4 per position (all loads first, then the LDS writes), one float4 per thread of the pixels
+        float4 st[(kLcMaxP * 8 + 255) / 256];
+#pragma unroll
+        for (int k = 0; k < (kLcMaxP * 8 + 255) / 256; ++k) {
+            const int idx = tid + k * 256, pos = idx >> 3, q = idx & 7;
+            st[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pos < P) {
+                const int j = pos / BW, i = pos - j * BW;
+                st[k] = *reinterpret_cast<const float4 *>(f1 + ((size_t)b * hw + (size_t)(by0 + j) * W + (bx0 + i)) * C + c0 + 4 * q);
+            }
+        }
+        {
+            const int pl = tid >> 3, q = tid & 7;
+            const int y = ty0 + pl / kLcTX, x = tx0 + pl % kLcTX;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y < H && x < W) v = *reinterpret_cast<const float4 *>(f0 + ((size_t)b * hw + (size_t)y * W + x) * C + c0 + 4 * q);
+            *reinterpret_cast<float4 *>(&fb[pl * kLcRow + 4 * q]) = v;
+        }
+#pragma unroll
+        for (int k = 0; k < (kLcMaxP * 8 + 255) / 256; ++k) {
+            const int idx = tid + k * 256, pos = idx >> 3, q = idx & 7;
+            if (pos < P) *reinterpret_cast<float4 *>(&fa[pos * kLcRow + 4 * q]) = st[k];
+        }
+        __syncthreads();
+        float4 bv[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) bv[s4] = *reinterpret_cast<const float4 *>(&fb[m * kLcRow + 16 * kh + 4 * s4]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int mb = wave + 4 * k;
+            if (mb < nblk) {                                                  // wave-uniform
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    // rows >= P of the last block hold stale LDS: their products stay in their own (never read) rows of D
+                    const float4 av = *reinterpret_cast<const float4 *>(&fa[(mb * 32 + m) * kLcRow + 16 * kh + 4 * s4]);
+                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[s4].x, acc[k], 0, 0, 0);
+                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[s4].y, acc[k], 0, 0, 0);
+                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv[s4].z, acc[k], 0, 0, 0);
+                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv[s4].w, acc[k], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                                      // the chunk is consumed
+    }
+    // D[position][pixel] -> LDS (over the chunk buffer): lane holds pixel n = lane % 32, rows (r & 3) + 8 (r >> 2) + 4 (lane / 32)
+    float *dl = fa;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int mb = wave + 4 * k;
+        if (mb < nblk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dl[(mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * 33 + m] = acc[k][r];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < NT * kLcTile; e += 256) {
+        const int t = e / kLcTile, pl = e - t * kLcTile;
+        const int y = ty0 + pl / kLcTX, x = tx0 + pl % kLcTX;
+        if (y >= H || x >= W) continue;
+        float v = 0.f;
+        if (slive[pl]) {
+            const int dy = t / D, dx = t - dy * D;
+            const int xx = sx0[pl] - R + dx, yy = sy0[pl] - R + dy;         // the tap's four positions: (xx, yy) .. (xx + 1, yy + 1)
+            const float wx1 = swx[pl], wy1 = swy[pl], wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+            const bool xa = xx >= 0 && xx < W, xb = xx + 1 >= 0 && xx + 1 < W, ya = yy >= 0 && yy < H, yb = yy + 1 >= 0 && yy + 1 < H;
+            const int base = ((yy - by0) * BW + (xx - bx0)) * 33 + pl;
+            const float d00 = (xa && ya) ? dl[base] : 0.f, d01 = (xb && ya) ? dl[base + 33] : 0.f;
+            const float d10 = (xa && yb) ? dl[base + BW * 33] : 0.f, d11 = (xb && yb) ? dl[base + (BW + 1) * 33] : 0.f;
+            v = ((wx0 * wy0) * d00 + (wx1 * wy0) * d01 + (wx0 * wy1) * d10 + (wx1 * wy1) * d11) * scale;
+        }
+        corr[((size_t)b * NT + t) * hw + (size_t)y * W + x] = v;
+    }
+}
+
 // attention.py:220-256: 3x3 (radius r) local window attention: q = q_proj(f) (tokens [B][HW][128]), kp = k_proj(f) (same
 // layout), value = flow [B][2][H][W]; zero padding of both keys and values (F.unfold).  One wave per pixel.
 __global__ __launch_bounds__(256) void local_attn_prop_kernel(const float *__restrict__ qf, const float *__restrict__ kf,
@@ -1911,6 +2115,14 @@ int ct_local_corr_flow_f32(const float *f0, const float *f1, const float *flow, 
                            void *stream) {
     if (!f0 || !f1 || !flow || !corr || batch < 0 || h < 2 || w < 2 || radius < 0 || radius > 4) return CT_E_BADARG;
     if (batch == 0) return CT_OK;
+    static const bool tile_form = [] { const char *e = getenv("CT_HIP_LCF_TILE"); return !(e && atoi(e) == 0); }();
+    if (tile_form && (reinterpret_cast<uintptr_t>(f0) & 15) == 0 && (reinterpret_cast<uintptr_t>(f1) & 15) == 0) {
+        const int tiles_x = (w + ct::kLcTX - 1) / ct::kLcTX, tiles_y = (h + ct::kLcTY - 1) / ct::kLcTY;
+        hipLaunchKernelGGL(ct::local_corr_flow_tile_kernel, dim3((unsigned)(tiles_x * tiles_y), batch), dim3(256), 0, (hipStream_t)stream, f0, f1,
+                           flow, corr, h, w, radius, 1.0f / sqrtf(128.0f), tiles_x);
+        CT_CHECK_LAUNCH();
+        return CT_OK;
+    }
     dim3 grid((unsigned)(((long long)h * w + ct::kLcfPix - 1) / ct::kLcfPix), batch);
     hipLaunchKernelGGL(ct::local_corr_flow_kernel, grid, dim3(256), 0, (hipStream_t)stream, f0, f1, flow, corr, h, w, radius,
                        1.0f / sqrtf(128.0f));

@@ -486,3 +486,42 @@ def test_space_to_depth_and_stride2_cache(hip):
     assert torch.equal(hip.space_to_depth2(view)[:, 5:10], view[:, :, 0::2, 1::2])
     with pytest.raises(hip.CtHipError):
         hip.space_to_depth2(rnd(1, 4, 7, 24).cuda())
+
+
+@pytest.mark.parametrize("kind", ["smooth", "constant", "jump", "random", "outside", "nan"])
+def test_local_corr_flow_tile_form(hip, kind):
+    """ct_local_corr_flow_f32 in its tile form (csrc/gmflow.hip: a 4 x 8 pixel tile shares the box of its windows in LDS, one float32
+    MFMA GEMM per tile) against the reference's grid_sample formulation (oracle/gmflow.py, float64): smooth flows (the shared box),
+    a flow discontinuity and random flows (boxes beyond the LDS budget: the per-pixel form inside the same launch), windows that
+    leave the image partly or entirely, NaN / inf flows, ragged tiles at the right / bottom edges"""
+    b, h, w = 2, 22, 43
+    f0, f1 = rnd(b, 128, h, w), rnd(b, 128, h, w)
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    if kind == "smooth":
+        flow = torch.stack([0.07 * xx - 0.03 * yy + 0.4, 0.05 * yy + 0.02 * xx - 1.3], 0)[None].repeat(b, 1, 1, 1)
+    elif kind == "constant":
+        flow = torch.full((b, 2, h, w), 2.25)
+        flow[:, 1] = -3.5
+    elif kind == "jump":
+        flow = torch.zeros(b, 2, h, w)
+        flow[:, 0, :, 17:] = 9.5                                  # a motion boundary through the tiles of column 16..23
+        flow[:, 1, 10:, :] = -6.25
+    elif kind == "random":
+        flow = rnd(b, 2, h, w) * 5
+    elif kind == "outside":
+        flow = torch.stack([0.9 * xx - 30.0, 0.0 * yy + 14.0], 0)[None].repeat(b, 1, 1, 1)     # windows leave the image on three sides
+        flow[1] = 300.0                                            # every window far outside: all zeros
+    else:
+        flow = rnd(b, 2, h, w)
+        flow[0, 0, 3, 5] = float("nan")
+        flow[1, 1, 20, 40] = float("inf")
+        flow[0, :, 8:12, 8:16] = float("nan")                     # a whole tile without a finite flow
+    t0, t1 = f0.flatten(2).transpose(1, 2).contiguous(), f1.flatten(2).transpose(1, 2).contiguous()
+    got = hip.local_corr_flow(t0.cuda(), t1.cuda(), flow.cuda(), 4).cpu().double()
+    fin = torch.isfinite(flow).all(dim=1, keepdim=True)
+    ref = og.local_correlation_with_flow(f0.double(), f1.double(), torch.where(fin, flow, torch.full_like(flow, 1e5)).double(), 4)
+    assert got.shape == ref.shape == (b, 81, h, w)
+    assert torch.isfinite(got).all()                               # a non-finite flow samples nothing: zeros (the clamp of the kernel)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=2e-4, err_msg=kind)
+    if kind == "outside":
+        assert got[1].abs().max().item() == 0.0
