@@ -1516,6 +1516,77 @@ __device__ __forceinline__ void lcf_window(const float *__restrict__ flow, int b
     y0 = (y0f > -1e6f && y0f < 1e6f) ? (int)y0f : -1000000;
 }
 
+// D[position][pixel] = <f1[box position], f0[tile pixel]> for the P <= kLcMaxP positions of the box (bx0, by0, width BW; inside the
+// image) and the 4 x 8 pixels of the tile at (tx0, ty0); result in fa as [position][33].  All 256 threads; ends with a barrier.
+__device__ __forceinline__ void lc_box_gemm(const float *__restrict__ f0, const float *__restrict__ f1, int b, size_t hw, int H, int W, int ty0,
+                                            int tx0, int bx0, int by0, int BW, int P, float *fa, float *fb) {
+    constexpr int C = 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblk = (P + 31) >> 5;
+    f32x16g acc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    const int m = lane & 31, kh = lane >> 5;
+    for (int c0 = 0; c0 < C; c0 += kLcChunk) {
+        // stage the chunk: 8 float4 per position (all loads first, then the LDS writes), one float4 per thread of the pixels
+        float4 st[(kLcMaxP * 8 + 255) / 256];
+#pragma unroll
+        for (int k = 0; k < (kLcMaxP * 8 + 255) / 256; ++k) {
+            const int idx = tid + k * 256, pos = idx >> 3, q = idx & 7;
+            st[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pos < P) {
+                const int j = pos / BW, i = pos - j * BW;
+                st[k] = *reinterpret_cast<const float4 *>(f1 + ((size_t)b * hw + (size_t)(by0 + j) * W + (bx0 + i)) * C + c0 + 4 * q);
+            }
+        }
+        {
+            const int pl = tid >> 3, q = tid & 7;
+            const int y = ty0 + pl / kLcTX, x = tx0 + pl % kLcTX;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y < H && x < W) v = *reinterpret_cast<const float4 *>(f0 + ((size_t)b * hw + (size_t)y * W + x) * C + c0 + 4 * q);
+            *reinterpret_cast<float4 *>(&fb[pl * kLcRow + 4 * q]) = v;
+        }
+#pragma unroll
+        for (int k = 0; k < (kLcMaxP * 8 + 255) / 256; ++k) {
+            const int idx = tid + k * 256, pos = idx >> 3, q = idx & 7;
+            if (pos < P) *reinterpret_cast<float4 *>(&fa[pos * kLcRow + 4 * q]) = st[k];
+        }
+        __syncthreads();
+        float4 bv[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) bv[s4] = *reinterpret_cast<const float4 *>(&fb[m * kLcRow + 16 * kh + 4 * s4]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int mb = wave + 4 * k;
+            if (mb < nblk) {                                                  // wave-uniform
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    // rows >= P of the last block hold stale LDS: their products stay in their own (never read) rows of D
+                    const float4 av = *reinterpret_cast<const float4 *>(&fa[(mb * 32 + m) * kLcRow + 16 * kh + 4 * s4]);
+                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[s4].x, acc[k], 0, 0, 0);
+                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[s4].y, acc[k], 0, 0, 0);
+                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv[s4].z, acc[k], 0, 0, 0);
+                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv[s4].w, acc[k], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                                      // the chunk is consumed
+    }
+    // D[position][pixel] -> LDS (over the chunk buffer): lane holds pixel n = lane % 32, rows (r & 3) + 8 (r >> 2) + 4 (lane / 32)
+    float *dl = fa;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int mb = wave + 4 * k;
+        if (mb < nblk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dl[(mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * 33 + m] = acc[k][r];
+        }
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void local_corr_flow_tile_kernel(const float *__restrict__ f0, const float *__restrict__ f1,
                                                                    const float *__restrict__ flow, float *__restrict__ corr, int H,
                                                                    int W, int R, float scale, int tiles_x) {
@@ -1610,69 +1681,9 @@ __global__ __launch_bounds__(256) void local_corr_flow_tile_kernel(const float *
         }
         return;
     }
-    const int P = (int)P64, nblk = (P + 31) >> 5;
-    f32x16g acc[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
-    const int m = lane & 31, kh = lane >> 5;
-    for (int c0 = 0; c0 < C && any; c0 += kLcChunk) {
-        // stage the chunk: 8 float4 per position (all loads first, then the LDS writes), one float4 per thread of the pixels
-        float4 st[(kLcMaxP * 8 + 255) / 256];
-#pragma unroll
-        for (int k = 0; k < (kLcMaxP * 8 + 255) / 256; ++k) {
-            const int idx = tid + k * 256, pos = idx >> 3, q = idx & 7;
-            st[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pos < P) {
-                const int j = pos / BW, i = pos - j * BW;
-                st[k] = *reinterpret_cast<const float4 *>(f1 + ((size_t)b * hw + (size_t)(by0 + j) * W + (bx0 + i)) * C + c0 + 4 * q);
-            }
-        }
-        {
-            const int pl = tid >> 3, q = tid & 7;
-            const int y = ty0 + pl / kLcTX, x = tx0 + pl % kLcTX;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (y < H && x < W) v = *reinterpret_cast<const float4 *>(f0 + ((size_t)b * hw + (size_t)y * W + x) * C + c0 + 4 * q);
-            *reinterpret_cast<float4 *>(&fb[pl * kLcRow + 4 * q]) = v;
-        }
-#pragma unroll
-        for (int k = 0; k < (kLcMaxP * 8 + 255) / 256; ++k) {
-            const int idx = tid + k * 256, pos = idx >> 3, q = idx & 7;
-            if (pos < P) *reinterpret_cast<float4 *>(&fa[pos * kLcRow + 4 * q]) = st[k];
-        }
-        __syncthreads();
-        float4 bv[4];
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) bv[s4] = *reinterpret_cast<const float4 *>(&fb[m * kLcRow + 16 * kh + 4 * s4]);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int mb = wave + 4 * k;
-            if (mb < nblk) {                                                  // wave-uniform
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    // rows >= P of the last block hold stale LDS: their products stay in their own (never read) rows of D
-                    const float4 av = *reinterpret_cast<const float4 *>(&fa[(mb * 32 + m) * kLcRow + 16 * kh + 4 * s4]);
-                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[s4].x, acc[k], 0, 0, 0);
-                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[s4].y, acc[k], 0, 0, 0);
-                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv[s4].z, acc[k], 0, 0, 0);
-                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv[s4].w, acc[k], 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();                                                      // the chunk is consumed
-    }
-    // D[position][pixel] -> LDS (over the chunk buffer): lane holds pixel n = lane % 32, rows (r & 3) + 8 (r >> 2) + 4 (lane / 32)
-    float *dl = fa;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int mb = wave + 4 * k;
-        if (mb < nblk) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dl[(mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * 33 + m] = acc[k][r];
-        }
-    }
-    __syncthreads();
+    const int P = (int)P64;
+    if (any) lc_box_gemm(f0, f1, b, hw, H, W, ty0, tx0, bx0, by0, BW, P, fa, fb);
+    const float *dl = fa;
     for (int e = tid; e < NT * kLcTile; e += 256) {
         const int t = e / kLcTile, pl = e - t * kLcTile;
         const int y = ty0 + pl / kLcTX, x = tx0 + pl % kLcTX;
@@ -1689,6 +1700,66 @@ __global__ __launch_bounds__(256) void local_corr_flow_tile_kernel(const float *
             v = ((wx0 * wy0) * d00 + (wx1 * wy0) * d01 + (wx0 * wy1) * d10 + (wx1 * wy1) * d11) * scale;
         }
         corr[((size_t)b * NT + t) * hw + (size_t)y * W + x] = v;
+    }
+}
+
+// local_corr_softmax_kernel for a 4 x 8 tile at once: the tile's (2R+1)^2 neighbourhoods are the box [tx0 - R, tx0 + 7 + R] x
+// [ty0 - R, ty0 + 3 + R] clipped to the image (192 positions for R = 4), one float32-MFMA GEMM (lc_box_gemm); then one wave per
+// pixel, lanes over taps, with the softmax and the expectation in the per-pixel kernel's own expressions and reduction order.
+__global__ __launch_bounds__(256) void local_corr_softmax_tile_kernel(const float *__restrict__ f0, const float *__restrict__ f1,
+                                                                      float *__restrict__ flow, int H, int W, int R, float scale, int tiles_x) {
+    __shared__ __attribute__((aligned(16))) float fa[kLcMaxP * kLcRow];
+    __shared__ __attribute__((aligned(16))) float fb[kLcTile * kLcRow];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int ty0 = ((int)blockIdx.x / tiles_x) * kLcTY, tx0 = ((int)blockIdx.x % tiles_x) * kLcTX;
+    const int D = 2 * R + 1, NT = D * D;
+    const size_t hw = (size_t)H * W;
+    const int bx0 = max(tx0 - R, 0), by0 = max(ty0 - R, 0);
+    const int BW = min(tx0 + kLcTX - 1 + R, W - 1) - bx0 + 1, BH = min(ty0 + kLcTY - 1 + R, H - 1) - by0 + 1;
+    lc_box_gemm(f0, f1, b, hw, H, W, ty0, tx0, bx0, by0, BW, BW * BH, fa, fb);      // (2R + 4) (2R + 8) <= kLcMaxP: checked by the launcher
+    const float *dl = fa;
+    for (int i = 0; i < kLcTile / 4; ++i) {
+        const int pl = wave * (kLcTile / 4) + i;
+        const int y = ty0 + pl / kLcTX, x = tx0 + pl % kLcTX;
+        if (y >= H || x >= W) continue;                                              // wave-uniform
+        float mx = -INFINITY;
+        float sc[2];
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+            const int t = lane + rep * 64;
+            float sv = -INFINITY;
+            if (t < NT) {
+                const int yy = y + t / D - R, xx = x + t % D - R;
+                sv = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? dl[((yy - by0) * BW + (xx - bx0)) * 33 + pl] * scale : -1e9f;   // matching.py:76
+            }
+            sc[rep] = sv;
+            mx = fmaxf(mx, sv);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        float sum = 0.f, ex = 0.f, ey = 0.f;
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+            const int t = lane + rep * 64;
+            if (t < NT) {
+                const float pr = expf(sc[rep] - mx);
+                sum += pr;
+                ex += pr * (float)(x + t % D - R);
+                ey += pr * (float)(y + t / D - R);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            sum += __shfl_xor(sum, off, 64);
+            ex += __shfl_xor(ex, off, 64);
+            ey += __shfl_xor(ey, off, 64);
+        }
+        if (lane == 0) {
+            const size_t pix = (size_t)y * W + x;
+            flow[((size_t)b * 2 + 0) * hw + pix] = ex / sum - (float)x;
+            flow[((size_t)b * 2 + 1) * hw + pix] = ey / sum - (float)y;
+        }
     }
 }
 
@@ -2104,6 +2175,15 @@ int ct_attention_colsum64_f32(const float *q, const float *k, const float *stats
 int ct_local_corr_softmax_f32(const float *f0, const float *f1, float *flow, int batch, int h, int w, int radius, void *stream) {
     if (!f0 || !f1 || !flow || batch < 0 || h < 1 || w < 1 || radius < 0 || (2 * radius + 1) * (2 * radius + 1) > 128) return CT_E_BADARG;
     if (batch == 0) return CT_OK;
+    static const bool tile_form = [] { const char *e = getenv("CT_HIP_LCF_TILE"); return !(e && atoi(e) == 0); }();
+    if (tile_form && (2 * radius + ct::kLcTY) * (2 * radius + ct::kLcTX) <= ct::kLcMaxP && (reinterpret_cast<uintptr_t>(f0) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(f1) & 15) == 0) {
+        const int tiles_x = (w + ct::kLcTX - 1) / ct::kLcTX, tiles_y = (h + ct::kLcTY - 1) / ct::kLcTY;
+        hipLaunchKernelGGL(ct::local_corr_softmax_tile_kernel, dim3((unsigned)(tiles_x * tiles_y), batch), dim3(256), 0, (hipStream_t)stream, f0, f1,
+                           flow, h, w, radius, 1.0f / sqrtf(128.0f), tiles_x);
+        CT_CHECK_LAUNCH();
+        return CT_OK;
+    }
     dim3 grid((unsigned)(((long long)h * w + 3) / 4), batch);
     hipLaunchKernelGGL(ct::local_corr_softmax_kernel, grid, dim3(256), 0, (hipStream_t)stream, f0, f1, flow, h, w, radius,
                        1.0f / sqrtf(128.0f));

@@ -525,3 +525,13 @@ def test_local_corr_flow_tile_form(hip, kind):
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=2e-4, err_msg=kind)
     if kind == "outside":
         assert got[1].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("b,h,w,r", [(2, 22, 43, 4), (1, 4, 8, 4), (1, 3, 5, 2), (2, 17, 64, 3)])
+def test_local_corr_softmax_tile_form(hip, b, h, w, r):
+    """ct_local_corr_softmax_f32 (tile form: the tile's neighbourhood box through one float32-MFMA GEMM) against matching.py:42-86 in
+    float64: images smaller than the window, ragged tiles, taps outside the image masked to -1e9"""
+    f0, f1 = rnd(b, 128, h, w), rnd(b, 128, h, w)
+    t0, t1 = f0.flatten(2).transpose(1, 2).contiguous(), f1.flatten(2).transpose(1, 2).contiguous()
+    close(hip.local_corr_softmax(t0.cuda(), t1.cuda(), h, w, r), og.local_correlation_softmax(f0.double(), f1.double(), r),
+          "local_correlation_softmax, tile form", atol=2e-4, rtol=1e-4)
