@@ -320,3 +320,38 @@ def test_conv_split_stream_k_many_launches_one_scratch(hip):
     for a_, b_ in zip(other, first):
         assert torch.equal(a_, b_)
     assert len(hip._sk_cache) >= 2
+
+
+def test_conv_split_stream_k_graph_replay_and_busy_gpu(hip):
+    """the shared form is plain stream work whose scratch cleans itself: captured in a hipGraph and replayed on new data it gives the
+    eager result bit for bit; with another stream keeping the CUs busy the producers are only delayed (workgroups are dispatched in
+    index order: a consumer's producer is never behind it) -- same bits, no give-up, flag words zero"""
+    cin, cout, h, w = 128, 128, 136, 240
+    x = rnd(2, cin, h, w).cuda()
+    wt, b = (rnd(cout, cin, 1, 5) / (cin * 5) ** 0.5).cuda(), rnd(cout).cuda()
+    wp, bp = hip.pack_gconv_weight(wt, b)
+    out = torch.empty((2, cout, h, w), device="cuda")
+    hip.gconv2d(x, wp, bp, cout, (1, 5), 1, (0, 2), out=out)              # warm: the stream's scratch exists
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        hip.gconv2d(x, wp, bp, cout, (1, 5), 1, (0, 2), out=out)
+    for _ in range(3):
+        x2 = rnd(2, cin, h, w).cuda()
+        want = hip.gconv2d(x2, wp, bp, cout, (1, 5), 1, (0, 2)).clone()
+        x.copy_(x2)
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
+    want = hip.gconv2d(x, wp, bp, cout, (1, 5), 1, (0, 2)).clone()
+    a = torch.randn(8192, 8192, device="cuda")
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(6):
+            a = a @ a * 1e-4
+    for _ in range(8):
+        assert torch.equal(hip.gconv2d(x, wp, bp, cout, (1, 5), 1, (0, 2)), want)
+    torch.cuda.synchronize()
+    assert hip.conv_stream_k_state() == (0, 0)
