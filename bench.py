@@ -375,6 +375,23 @@ def main():
                 ms = sorted(a.elapsed_time(b) for a, b in ev)
                 return {"median_ms": float(np.median(ms)), "min_ms": ms[0], "n": n, "warmup": warm, "timer": "HIP events"}
             extra["reinhard_pairs_per_s_transfer_only"] = B * rate(lambda: ct_hip.reinhard(tgt, ref, out=out), n=200)
+            # two batches in flight on two streams: the next batch's statistics sweep (issue bound) runs into the tail of this batch's
+            # apply sweep (HBM bound).  The headline keeps ONE stream (its per-kernel rooflines stay clean); this is what a pipelined
+            # caller gets from the same entry (tools/bench_reinhard_streams.py)
+            if gt is not None:
+                two = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
+                bufs = [(torch.empty_like(out), torch.zeros((B, 2), dtype=torch.float64, device=device)) for _ in range(2)]
+                def pipelined(n):
+                    torch.cuda.synchronize(device)
+                    t0 = time.perf_counter()
+                    for i in range(n):
+                        with torch.cuda.stream(two[i & 1]):
+                            ct_hip.reinhard_psnr(tgt, ref, gt, out=bufs[i & 1][0], psnr_out=bufs[i & 1][1])
+                    torch.cuda.synchronize(device)
+                    return n / (time.perf_counter() - t0)
+                pipelined(20)
+                extra["reinhard_pairs_per_s_with_psnr_two_streams"] = B * pipelined(200)
+                del bufs, two
             # the one-launch form (csrc/reinhard_persist.hip): float32 frames by name, uint8 frames through the u8 front door
             pr = torch.zeros((B, 2), dtype=torch.float64, device=device)
             extra["reinhard_persist_f32_pairs_per_s_with_psnr"] = B * rate(lambda: ct_hip.reinhard_persist(tgt, ref, gt=gt, out=out, psnr_out=pr), n=100)
