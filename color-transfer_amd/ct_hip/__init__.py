@@ -956,11 +956,13 @@ def space_to_depth2(x):
     # the SAME tensor object, unchanged, on the same stream (an address can be reused by another tensor: identity, not data_ptr)
     hit = _s2d_last[0]
     stream = torch.cuda.current_stream(x.device).cuda_stream
-    if hit is not None and hit[0]() is x and hit[1] == (x._version, stream):
+    capturing = torch.cuda.is_current_stream_capturing()      # a graph must contain the kernel that makes what its convolutions read
+    if not capturing and hit is not None and hit[0]() is x and hit[1] == (x._version, stream):
         return _s2d_last[1]
     out = torch.empty((n, 4 * c, h // 2, w // 2), dtype=torch.float32, device=x.device)
     check(lib().ct_space_to_depth2_f32(_ptr(x), _ptr(out), n, c, h, w, _nchw_bstride(x), _stream()))
-    _s2d_last[0], _s2d_last[1] = (weakref.ref(x), (x._version, stream)), out
+    if not capturing:
+        _s2d_last[0], _s2d_last[1] = (weakref.ref(x), (x._version, stream)), out
     return out
 
 

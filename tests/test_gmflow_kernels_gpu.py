@@ -535,3 +535,21 @@ def test_local_corr_softmax_tile_form(hip, b, h, w, r):
     t0, t1 = f0.flatten(2).transpose(1, 2).contiguous(), f1.flatten(2).transpose(1, 2).contiguous()
     close(hip.local_corr_softmax(t0.cuda(), t1.cuda(), h, w, r), og.local_correlation_softmax(f0.double(), f1.double(), r),
           "local_correlation_softmax, tile form", atol=2e-4, rtol=1e-4)
+
+
+def test_stride2_conv_in_a_graph_reads_fresh_data(hip):
+    """the cached space-to-depth image is never used inside a capture: a replayed graph convolves what is in its input NOW"""
+    x = rnd(2, 64, 24, 64).cuda()
+    wt, b = (rnd(96, 64, 3, 3) / 24).cuda(), rnd(96).cuda()
+    wp, bp = hip.pack_gconv_weight(wt, b)
+    out = torch.empty((2, 96, 12, 32), device="cuda")
+    hip.gconv2d(x, wp, bp, 96, (3, 3), 2, (1, 1), out=out)               # warm (and fills the cache for this very tensor object)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        hip.gconv2d(x, wp, bp, 96, (3, 3), 2, (1, 1), out=out)
+    x2 = rnd(2, 64, 24, 64).cuda()
+    x.copy_(x2)
+    graph.replay()
+    torch.cuda.synchronize()
+    close(out, F.conv2d(x2.cpu().double(), wt.cpu().double(), b.cpu().double(), stride=2, padding=1), "stride-2 conv replayed on new data")
