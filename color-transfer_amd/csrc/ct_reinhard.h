@@ -35,15 +35,21 @@ __device__ __forceinline__ void accumulate(double (&s)[LAB ? 6 : 9], const doubl
 }
 
 // shifted sums of (fy, fx-fy, fy-fz) around pivot k over n pixels -> the Lab stats record {mean L,a,b ; std L,a,b ; n ; 0}
-__device__ __forceinline__ void lab_record(const double *s, const double *k, double n, double *o) {
+// floor: variances at or below it are zero.  The float32 sweeps pass kVarFloorF32: their shifted sums of a CONSTANT image leave a
+// cancellation residue of either sign (<= (2^-11)^2 x 1e-7, the pivot sits on a 2^-10 grid), and the reference's own sigma of a
+// constant image is 0 or 1e-17 by the luck of its pairwise sum (inf / nan or finite garbage): here it is exactly 0 -> inf / nan,
+// deterministically.  (A frame with a true sigma below 2e-5 L* is constant to one part in a million.)
+constexpr double kVarFloorF32 = 3e-14;
+__device__ __forceinline__ double var_to_sd(double v, double floor) { return sqrt(v > floor ? v : (v == v ? 0.0 : v)); }
+__device__ __forceinline__ void lab_record(const double *s, const double *k, double n, double *o, double floor = 0.0) {
     const double m0 = s[0] / n, m1 = s[1] / n, m2 = s[2] / n;  // mean of (x - K)
     // (fy, fx-fy, fy-fz) -> (L, a, b): scale 116/500/200, offset -16/0/0
     o[0] = fma(116.0, k[0] + m0, -16.0); o[1] = 500.0 * (k[1] + m1); o[2] = 200.0 * (k[2] + m2);
     // population variance (np.std, ddof 0); clamp the cancellation residue of constant images
     const double v0 = fma(-s[0], m0, s[3]) / n, v1 = fma(-s[1], m1, s[4]) / n, v2 = fma(-s[2], m2, s[5]) / n;
-    o[3] = 116.0 * sqrt(v0 > 0.0 ? v0 : (v0 == v0 ? 0.0 : v0));
-    o[4] = 500.0 * sqrt(v1 > 0.0 ? v1 : (v1 == v1 ? 0.0 : v1));
-    o[5] = 200.0 * sqrt(v2 > 0.0 ? v2 : (v2 == v2 ? 0.0 : v2));
+    o[3] = 116.0 * var_to_sd(v0, floor);
+    o[4] = 500.0 * var_to_sd(v1, floor);
+    o[5] = 200.0 * var_to_sd(v2, floor);
     o[6] = n; o[7] = 0.0;
 }
 
@@ -64,6 +70,15 @@ __device__ __forceinline__ ReinhardCoef reinhard_coef(const double *st, const do
     c.ca = fma(-st[1], c.sa, sr[1]) * (1.0 / 500.0);
     c.cb = fma(-st[2], c.sb, sr[2]) * (1.0 / 200.0);
     return c;
+}
+
+// The float32 table path (ct_color_lut.h) keeps its error budget (Lab <= 5e-5) for moderate maps only: its forward error is
+// multiplied by the scales.  Everything else -- and inf / nan coefficients (a constant target, like the reference) -- takes the
+// exact float64 code.
+constexpr double kFastScale = 4.0, kFastOffset = 8.0;
+__device__ __forceinline__ bool reinhard_coef_fast(const ReinhardCoef &c) {
+    const double smax = fmax(fmax(fabs(c.sL), fabs(c.sa)), fabs(c.sb)), omax = fmax(fmax(fabs(c.cy), fabs(c.ca)), fabs(c.cb));
+    return (smax <= kFastScale) & (omax <= kFastOffset);          // false for NaN
 }
 
 template <typename T, bool OUT_LAB>
@@ -104,11 +119,13 @@ __device__ __forceinline__ void store_tile(float *tile, int lane, const float (&
     for (int j = 0; j < 4; ++j) *reinterpret_cast<float3u *>(tile + (j * kWave + lane) * 3) = float3v{e[3 * j], e[3 * j + 1], e[3 * j + 2]};
 }
 
+__device__ __forceinline__ uint32_t max3u(uint32_t a, uint32_t b, uint32_t c) { return max(max(a, b), c); }      // v_max3_u32
 __device__ __forceinline__ uint32_t max_bits12(const float (&e)[12]) {
-    uint32_t m = 0;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) m = max(m, __float_as_uint(e[i]));
-    return m;
+    const uint32_t m0 = max3u(__float_as_uint(e[0]), __float_as_uint(e[1]), __float_as_uint(e[2]));
+    const uint32_t m1 = max3u(__float_as_uint(e[3]), __float_as_uint(e[4]), __float_as_uint(e[5]));
+    const uint32_t m2 = max3u(__float_as_uint(e[6]), __float_as_uint(e[7]), __float_as_uint(e[8]));
+    const uint32_t m3 = max3u(__float_as_uint(e[9]), __float_as_uint(e[10]), __float_as_uint(e[11]));
+    return max(max3u(m0, m1, m2), m3);
 }
 
 // rotate the four pixels of a lane by one: the exact fallback stays a rolled loop over "pixel 0" (one copy of the code,

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kBlock) CT_WPE void moments_kernel(const T *__restr
 template <bool LAB>
 __global__ __launch_bounds__(kBlock) void moments_finalize_kernel(const double *__restrict__ partials,
                                                                   const double *__restrict__ pivots, int n_blocks,
-                                                                  int64_t n_pixels, double *__restrict__ stats) {
+                                                                  int64_t n_pixels, double *__restrict__ stats, double var_floor) {
     constexpr int NV = LAB ? 6 : 9;
     __shared__ double lds[4 * NV];
     const int img = blockIdx.x;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kBlock) void moments_finalize_kernel(const double *
         const double *k = pivots + img * kPivotStride;
         const double m0 = s[0] / n, m1 = s[1] / n, m2 = s[2] / n;  // mean of (x - K)
         if (LAB) {
-            lab_record(s, k, n, stats + (size_t)img * CT_LAB_STATS_STRIDE);
+            lab_record(s, k, n, stats + (size_t)img * CT_LAB_STATS_STRIDE, var_floor);
         } else {
             double *o = stats + (size_t)img * CT_RGB_STATS_STRIDE;
             o[0] = k[0] + m0; o[1] = k[1] + m1; o[2] = k[2] + m2;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_STATS) void lab_moments_lut_k
                                                                                       const float *__restrict__ base1, int n_first,
                                                                                       int64_t n_pixels, double *__restrict__ partials,
                                                                                       double *__restrict__ pivots) {
-    __shared__ __attribute__((aligned(16))) unsigned char tab[lut::kLdsBytesF32];
+    __shared__ __attribute__((aligned(16))) unsigned char tab[lut::kLdsBytesFwd];
     __shared__ double red[kLutWaves * 6];
     __shared__ float piv[3];
     const int img = blockIdx.y;
@@ -245,19 +245,19 @@ __global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_STATS) void lab_moments_lut_k
 #endif
     float p0[3] = {0.f, 0.f, 0.f};
     if (threadIdx.x == 0 && n_pixels > 0) { p0[0] = p[0]; p0[1] = p[1]; p0[2] = p[2]; }
-    lut::load_tables_f32<kLutBlock>(tab);
+    lut::load_tables<kLutBlock, false>(tab);
     __syncthreads();
     // Pivot of the shifted sums: the values of pixel 0 of the image (any point inside the data's range keeps the variance
     // well conditioned), put on a 2^-10 grid: (a float32 difference, on a 2^-26 grid) - (a pivot with finer bits) would round
     // the SAME way for every pixel -- a bias of half an ulp (measured: 4e-9, i.e. 2e-6 in mean a*).  Out-of-range pixel 0: 0.5.
     if (threadIdx.x == 0) {
-        float fx = 0.5f, fy = 0.5f, fz = 0.5f;
+        float fy = 0.5f, dxy = 0.0f, dyz = 0.0f;
         if (max(max(__float_as_uint(p0[0]), __float_as_uint(p0[1])), __float_as_uint(p0[2])) <= lut::kOneBits) {
-            lut::rgb_to_f32(tab, p0[0], p0[1], p0[2], fx, fy, fz);
+            lut::rgb_to_f_stats(tab, p0[0], p0[1], p0[2], fy, dxy, dyz);
         }
         piv[0] = rintf(fy * 1024.0f) * (1.0f / 1024.0f);
-        piv[1] = rintf((fx - fy) * 1024.0f) * (1.0f / 1024.0f);
-        piv[2] = rintf((fy - fz) * 1024.0f) * (1.0f / 1024.0f);
+        piv[1] = rintf(dxy * 1024.0f) * (1.0f / 1024.0f);
+        piv[2] = rintf(dyz * 1024.0f) * (1.0f / 1024.0f);
     }
     __syncthreads();
     const float kf[3] = {__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(piv[0]))),
@@ -289,9 +289,9 @@ __global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_STATS) void lab_moments_lut_k
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float fx, fy, fz;
-                lut::rgb_to_f32(tab, c[3 * q], c[3 * q + 1], c[3 * q + 2], fx, fy, fz);
-                const float dx = fy - kf[0], dy = (fx - fy) - kf[1], dz = (fy - fz) - kf[2];
+                float fy, dxy, dyz;
+                lut::rgb_to_f_stats(tab, c[3 * q], c[3 * q + 1], c[3 * q + 2], fy, dxy, dyz);
+                const float dx = fy - kf[0], dy = dxy - kf[1], dz = dyz - kf[2];
                 sf[0] += dx; sf[1] += dy; sf[2] += dz;
                 sf[3] = fmaf(dx, dx, sf[3]); sf[4] = fmaf(dy, dy, sf[4]); sf[5] = fmaf(dz, dz, sf[5]);
             }
@@ -357,7 +357,9 @@ __global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_STATS) void lab_moments_lut_k
     }
 }
 
-// A2 on the table path, float64-grade (a* = 500 (fx - fy) must be right per pixel).
+// A2 on the table path: float32 difference forms (ct_color_lut.h: a* = 500 (fx - fy) must be right per pixel).  Affine scales
+// above kFastScale (the forward error grows with them), pixels outside [0,1] and pixels within rounding of a kink of Lab's f()
+// take the exact float64 code, tile by tile.
 template <bool OUT_LAB>
 __global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_APPLY) void reinhard_apply_lut_kernel(const float *__restrict__ target,
                                                                                          const double *__restrict__ stats_t,
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_APPLY) void reinhard_apply_lu
                 sum[m] = ((((((f[0] + f[1]) + f[2]) + f[3]) + f[4]) + f[5]) + f[6]) + f[7];
             }
             double *rec = fin + 96 + threadIdx.x * CT_LAB_STATS_STRIDE;
-            lab_record(sum, pivots + image * kPivotStride, (double)n_pixels, rec);
+            lab_record(sum, pivots + image * kPivotStride, (double)n_pixels, rec, kVarFloorF32);      // the fused call: float32 sweep
             if (blockIdx.x == 0 && stats_out != nullptr) {
 #pragma unroll
                 for (int m = 0; m < CT_LAB_STATS_STRIDE; ++m) stats_out[(size_t)image * CT_LAB_STATS_STRIDE + m] = rec[m];
@@ -421,10 +423,10 @@ __global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_APPLY) void reinhard_apply_lu
     ReinhardCoef c = reinhard_coef(rec_t, rec_r);
     c.sL = uniform_f64(c.sL); c.sa = uniform_f64(c.sa); c.sb = uniform_f64(c.sb);
     c.cy = uniform_f64(c.cy); c.ca = uniform_f64(c.ca); c.cb = uniform_f64(c.cb);
-    // the table path needs finite, moderate coefficients (then every intermediate is finite); anything else -- a
-    // constant target gives inf / nan like the reference -- goes through the exact code
-    const double cmax = fmax(fmax(fmax(fabs(c.sL), fabs(c.sa)), fmax(fabs(c.sb), fabs(c.cy))), fmax(fabs(c.ca), fabs(c.cb)));
-    const bool coef_bad = !(cmax < 1e6);
+    // the table path needs finite, moderate coefficients (every intermediate finite, the float32 error budget kept); anything
+    // else -- a constant target gives inf / nan like the reference -- goes through the exact code
+    const bool coef_bad = !reinhard_coef_fast(c);
+    const float sLf = (float)c.sL, saf = (float)c.sa, sbf = (float)c.sb, cyf = (float)c.cy, caf = (float)c.ca, cbf = (float)c.cb;
     double sq = 0.0;
     __syncthreads();
     auto apply_one = [&](float (&cc)[12], int64_t tt) {
@@ -433,39 +435,39 @@ __global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_APPLY) void reinhard_apply_lu
         float gv[12];
         if (gt != nullptr) load_tile(gt + ((size_t)img * n_pixels + (size_t)tt * kTilePixels) * 3, lane, gv);
 #endif
+        bool slow = false, skip = false;
 #ifdef CT_ABL_NOMATH
-        if (true) {
+        skip = true;
 #pragma unroll
-            for (int i = 0; i < 12; ++i) w[i] = cc[i] * (float)c.sL;
-        } else
+        for (int i = 0; i < 12; ++i) w[i] = cc[i] * sLf;
 #endif
-#ifdef CT_ABL_NOSLOW
-        if (false) {
-#else
-        if (coef_bad || __builtin_amdgcn_ballot_w64(max_bits12(cc) > lut::kOneBits)) {
+#ifndef CT_ABL_NOSLOW
+        slow = coef_bad || __builtin_amdgcn_ballot_w64(max_bits12(cc) > lut::kOneBits);
 #endif
+        if (!slow && !skip) {
+            bool near = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float fy, dxy, dyz;
+                near |= lut::rgb_to_f(tab, cc[3 * q], cc[3 * q + 1], cc[3 * q + 2], fy, dxy, dyz);
+                const float gy = fmaf(sLf, fy, cyf), dx = fmaf(saf, dxy, caf), dz = fmaf(sbf, dyz, cbf);
+                if (OUT_LAB) {
+                    w[3 * q] = fmaf(116.0f, gy, -16.0f); w[3 * q + 1] = 500.0f * dx; w[3 * q + 2] = 200.0f * dz;
+                } else {
+                    near |= lut::f_to_rgb_clip(tab, gy, dx, dz, w[3 * q], w[3 * q + 1], w[3 * q + 2]);
+                }
+            }
+#ifndef CT_ABL_NOSLOW
+            slow = __builtin_amdgcn_ballot_w64(near) != 0;        // a pixel within rounding of a kink of f(): the whole tile again, exactly
+#endif
+        }
+        if (slow && !skip) {
 #pragma unroll 1
             for (int q = 0; q < 4; ++q) {
                 rotate_pixels(w);                      // the result of pixel q lands in slot 3 and ends in slot q
                 reinhard_pixel<float, OUT_LAB>(c, (double)cc[0], (double)cc[1], (double)cc[2], w[9], w[10], w[11]);
                 rotate_pixels(cc);
                 asm volatile("" : "+v"(cc[0]));       // keep the loop rolled
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                double fx, fy, fz;
-                lut::rgb_to_f(tab, cc[3 * q], cc[3 * q + 1], cc[3 * q + 2], fx, fy, fz);
-                const double gy = fma(c.sL, fy, c.cy);
-                const double gx = gy + fma(c.sa, fx - fy, c.ca);
-                const double gz = gy - fma(c.sb, fy - fz, c.cb);
-                if (OUT_LAB) {
-                    double L, A, B;
-                    f_to_lab(gx, gy, gz, L, A, B);
-                    w[3 * q] = (float)L; w[3 * q + 1] = (float)A; w[3 * q + 2] = (float)B;
-                } else {
-                    lut::f_to_rgb_clip(tab, gx, gy, gz, w[3 * q], w[3 * q + 1], w[3 * q + 2]);
-                }
             }
         }
 #ifdef CT_ABL_NOSTORE
@@ -820,7 +822,7 @@ static int launch_moments(const T *base0, const T *base1, int n_first, int n_ima
         return CT_OK;
     }
     hipLaunchKernelGGL((moments_finalize_kernel<LAB>), dim3(n_images), dim3(kBlock), 0, s, l.partials, l.pivots, G,
-                       n_pixels, stats);
+                       n_pixels, stats, use_lut ? kVarFloorF32 : 0.0);
     CT_CHECK_LAUNCH();
     return CT_OK;
 }

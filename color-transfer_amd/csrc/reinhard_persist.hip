@@ -7,8 +7,9 @@
 //
 //   R(p)  streams its share of the reference of pair p        -> shifted moments of (fy, fx - fy, fy - fz)
 //   T(p)  streams its share of the target, forward transform  -> moments, AND parks (fy, fx - fy, fy - fz) of every pixel in
-//         LDS as 2^-30 fixed point (12 bytes per pixel, the size of the float32 pixel itself: 8100 pixels = 97 KB at 1080p
-//         beside 37 KB of tables); a tile with a value outside [0, 1] parks its raw pixels instead
+//         LDS as a float32 triple (12 bytes per pixel, the size of the float32 pixel itself; the float32 difference forms of
+//         ct_color_lut.h: no float64 instruction per pixel anywhere in this kernel); a tile with a value outside [0, 1], or with
+//         a pixel within rounding of a kink of Lab's f(), is marked and applied with the exact code from memory
 //   publish(p): the workgroup's 12 sums go out as ONE wave instruction of 64-bit integer atomic adds
 //   A(p)  affine map + inverse transform + gamma + clip out of LDS, result written once; with a ground-truth frame the squared
 //         error of the per-frame PSNR (methods/__init__.py:32) is taken from the registers that hold the result
@@ -68,8 +69,7 @@ struct Scratch {
     unsigned long long rec[kShards * kDataWords];
     float piv[2 * kMaxPairs][4];      // pivot of the shifted sums per image (2^-10 grid)
     float lut255[256];                // uint8 frames: (float)k / 255
-    double lin255[256];               // uint8 frames: gamma expansion of lut255[k]
-    float lin255f[256];               // the same rounded to float32 (statistics of the reference frame)
+    float lin255f[256];               // uint8 frames: gamma expansion of lut255[k] (table E)
     unsigned cnt[2];
     unsigned ticket[2];               // arrivals of the waves at A(p), by pair parity: the first one collects the statistics
     unsigned ready[2];                // p + 1 once the coefficients of pair p are in coef[p & 1]
@@ -112,9 +112,6 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
     CT_DPP_ADD(0x143, 0xc);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
 #undef CT_DPP_ADD
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-__device__ __forceinline__ uint32_t fix30(double v) {           // round(v 2^30) as a 32-bit two's complement word (|v| < 2)
-    return (uint32_t)__double2loint(fma(v, 0x1p30, 0x1.8p52));
 }
 __device__ __forceinline__ uint64_t realtime() { return __builtin_amdgcn_s_memrealtime(); }     // 100 MHz
 constexpr uint64_t kSpinTicks = 200000000ull;                    // 2 s
@@ -179,8 +176,10 @@ __device__ __forceinline__ void exact_moments_tile(const T *tile, const float (&
 
 // ---- forward transform of one tile + its shifted moments; PARK: leave what the apply phase needs in the wave's LDS slot ----
 // slot layout: dword (3 j + c) * 64 + lane = component c of the lane's pixel j (conflict-free ds_write_b32 / ds_read_b32, and
-// nothing of the tile has to wait in registers for its neighbours)
+// nothing of the tile has to wait in registers for its neighbours); the parked value is the float32 triple (fy, fx - fy, fy - fz)
 // STATS = false: the forward transform alone (a target tile fetched a second time during the apply stage)
+// Returns true when the apply phase must take the exact code for this tile (from memory): a value outside [0, 1] / a NaN, or a
+// pixel within rounding of the kink of Lab's f() (ct_color_lut.h).
 template <typename T, bool PARK, bool STATS = true>
 __device__ __forceinline__ bool fwd_tile(const unsigned char *tab, Scratch *sc, const void *tile, typename Tile<T>::Raw &cur, const float (&kf)[3],
                                          float (&sf)[6], uint32_t *slot, int w, int lane) {
@@ -190,51 +189,50 @@ __device__ __forceinline__ bool fwd_tile(const unsigned char *tab, Scratch *sc, 
     const bool raw = !Tile<T>::in_range(cur);
 #endif
     if constexpr (sizeof(T) == 4) {
-        if (raw) {                       // some value outside [0, 1] or NaN: park the raw pixels, moments by the exact code
-            if (PARK) {
-#pragma unroll
-                for (int i = 0; i < 12; ++i) slot[i * kWave + lane] = __float_as_uint(cur.e[i]);
-            }
+        if (raw) {                       // some value outside [0, 1] or NaN: moments by the exact code
             if (STATS) exact_moments_tile<T>(reinterpret_cast<const T *>(tile), kf, &sc->side[w][0], lane);
+            return true;
         }
     }
-    if (!raw) {
+    bool near = false;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if constexpr (!PARK) {
-                // the reference frame only feeds the statistics: float32 arithmetic (what the reference itself does for float32
-                // frames, and what the two-sweep statistics kernel does), unbiased per pixel
-                float gx, gy, gz;
-                if constexpr (sizeof(T) == 4) lut::rgb_to_f32_a(tab, cur.e[3 * q], cur.e[3 * q + 1], cur.e[3 * q + 2], gx, gy, gz);
-                else lut::lin32_to_f32(sc->lin255f[byte_of(cur.d, 3 * q)], sc->lin255f[byte_of(cur.d, 3 * q + 1)], sc->lin255f[byte_of(cur.d, 3 * q + 2)], gx, gy, gz);
-                const float e0 = gy - kf[0], e1 = (gx - gy) - kf[1], e2 = (gy - gz) - kf[2];
-                sf[0] += e0; sf[1] += e1; sf[2] += e2;
-                sf[3] = fmaf(e0, e0, sf[3]); sf[4] = fmaf(e1, e1, sf[4]); sf[5] = fmaf(e2, e2, sf[5]);
-                CT_RP_PIXEL_FENCE(q);
-                continue;
-            }
-            double fx, fy, fz;
+    for (int q = 0; q < 4; ++q) {
+        float fy, dxy, dyz;
+        if constexpr (!PARK) {
+            // the reference frame only feeds the statistics: plain float32 values of f(), unbiased per pixel
             if constexpr (sizeof(T) == 4) {
-                lut::rgb_to_f(tab, cur.e[3 * q], cur.e[3 * q + 1], cur.e[3 * q + 2], fx, fy, fz);
+                lut::rgb_to_f_stats(tab, cur.e[3 * q], cur.e[3 * q + 1], cur.e[3 * q + 2], fy, dxy, dyz);
             } else {
-                lut::lin_to_f(tab, sc->lin255[byte_of(cur.d, 3 * q)], sc->lin255[byte_of(cur.d, 3 * q + 1)], sc->lin255[byte_of(cur.d, 3 * q + 2)], fx, fy, fz);
+                const float l[3] = {sc->lin255f[byte_of(cur.d, 3 * q)], sc->lin255f[byte_of(cur.d, 3 * q + 1)], sc->lin255f[byte_of(cur.d, 3 * q + 2)]};
+                lut::lin_to_f_stats(tab, l, fy, dxy, dyz);
             }
-            const double dxy = fx - fy, dyz = fy - fz;
-            // moments in float32 around a pivot on a 2^-10 grid: the conversions round to nearest (unbiased), the subtractions are exact
-            if (STATS) {
-                const float e0 = (float)fy - kf[0], e1 = (float)dxy - kf[1], e2 = (float)dyz - kf[2];
-                sf[0] += e0; sf[1] += e1; sf[2] += e2;
-                sf[3] = fmaf(e0, e0, sf[3]); sf[4] = fmaf(e1, e1, sf[4]); sf[5] = fmaf(e2, e2, sf[5]);
+        } else {
+            if constexpr (sizeof(T) == 4) {
+                near |= lut::rgb_to_f(tab, cur.e[3 * q], cur.e[3 * q + 1], cur.e[3 * q + 2], fy, dxy, dyz);
+            } else {
+                const float l[3] = {sc->lin255f[byte_of(cur.d, 3 * q)], sc->lin255f[byte_of(cur.d, 3 * q + 1)], sc->lin255f[byte_of(cur.d, 3 * q + 2)]};
+                near |= lut::lin_to_f(tab, l, fy, dxy, dyz);
             }
-            if (PARK) {
-                slot[(3 * q) * kWave + lane] = fix30(fy);
-                slot[(3 * q + 1) * kWave + lane] = fix30(dxy);
-                slot[(3 * q + 2) * kWave + lane] = fix30(dyz);
-            }
-            CT_RP_PIXEL_FENCE(q);
         }
+        // moments in float32 around a pivot on a 2^-10 grid
+        if (STATS) {
+            const float e0 = fy - kf[0], e1 = dxy - kf[1], e2 = dyz - kf[2];
+            sf[0] += e0; sf[1] += e1; sf[2] += e2;
+            sf[3] = fmaf(e0, e0, sf[3]); sf[4] = fmaf(e1, e1, sf[4]); sf[5] = fmaf(e2, e2, sf[5]);
+        }
+        if (PARK) {
+            slot[(3 * q) * kWave + lane] = __float_as_uint(fy);
+            slot[(3 * q + 1) * kWave + lane] = __float_as_uint(dxy);
+            slot[(3 * q + 2) * kWave + lane] = __float_as_uint(dyz);
+        }
+        CT_RP_PIXEL_FENCE(q);
     }
-    return raw;
+#ifdef CT_RP_NOEXACT
+    return false;
+#else
+    // (the statistics keep the float32 value of a pixel next to the kink: 3.4e-7 on one pixel of two million)
+    return PARK && __builtin_amdgcn_ballot_w64(near) != 0;
+#endif
 }
 
 // ---- affine map + inverse transform of one parked tile, result stored, squared error against gv accumulated ----------------------
@@ -244,26 +242,44 @@ template <typename T> __device__ __forceinline__ void store_pixel(float *tile, i
 
 template <typename T, bool HAS_GT>
 __device__ __forceinline__ void apply_tile(const unsigned char *tab, const Scratch *sc, const uint32_t *slot, bool raw, bool coef_bad,
-                                           const ReinhardCoef &c, double sLs, double sas, double sbs, const void *tgt_tile, const void *gt_tile,
+                                           const ReinhardCoef &c, const float (&cf)[6], const void *tgt_tile, const void *gt_tile,
                                            float *out_tile, const typename Tile<T>::Raw &gv, double &sq, int lane) {
     float e = 0.f;
     auto gt_of = [&](int i) -> float {
         if constexpr (sizeof(T) == 4) return gv.e[i]; else return sc->lut255[byte_of(gv.d, i)];
     };
+    bool slow = raw || coef_bad;
 #ifdef CT_RP_NOEXACT
-    if (false) {
-#else
-    if (raw || coef_bad) {               // exact float64 code from the raw pixels (parked, or re-read when only the coefficients are odd)
+    slow = false;
 #endif
+    if (!slow) {
+        bool near = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float fy = __uint_as_float(slot[(3 * q) * kWave + lane]), dxy = __uint_as_float(slot[(3 * q + 1) * kWave + lane]),
+                        dyz = __uint_as_float(slot[(3 * q + 2) * kWave + lane]);
+            // fy' = sL fy + cy ; fx' - fy' = sa (fx - fy) + ca ; fy' - fz' = sb (fy - fz) + cb
+            const float gy = fmaf(cf[0], fy, cf[3]), dx = fmaf(cf[1], dxy, cf[4]), dz = fmaf(cf[2], dyz, cf[5]);
+            float r, g, b;
+            near |= lut::f_to_rgb_clip(tab, gy, dx, dz, r, g, b);
+            store_pixel<T>(out_tile, lane, q, r, g, b);
+            if (HAS_GT) {
+                const float d0 = r - gt_of(3 * q), d1 = g - gt_of(3 * q + 1), d2 = b - gt_of(3 * q + 2);
+                e = fmaf(d0, d0, e); e = fmaf(d1, d1, e); e = fmaf(d2, d2, e);
+            }
+            CT_RP_PIXEL_FENCE(q);
+        }
+#ifndef CT_RP_NOEXACT
+        slow = __builtin_amdgcn_ballot_w64(near) != 0;      // a pixel within rounding of the kink of the inverse: the tile again, exactly
+#endif
+    }
+    if (slow) {                          // exact float64 code from the pixels in memory (the tile was fetched a stage ago at most)
+        e = 0.f;
 #pragma unroll 1
         for (int q = 0; q < 4; ++q) {
             const int px = pixel_of<T>(lane, q);
             double r, g, b;
-            if (raw) {
-                r = __uint_as_float(slot[(3 * q) * kWave + lane]); g = __uint_as_float(slot[(3 * q + 1) * kWave + lane]); b = __uint_as_float(slot[(3 * q + 2) * kWave + lane]);
-            } else {
-                load_pixel<T>(reinterpret_cast<const T *>(tgt_tile) + px * 3, r, g, b);
-            }
+            load_pixel<T>(reinterpret_cast<const T *>(tgt_tile) + px * 3, r, g, b);
             float o0, o1, o2;
             reinhard_pixel<float, false>(c, r, g, b, o0, o1, o2);
             *reinterpret_cast<float3u *>(out_tile + px * 3) = float3v{o0, o1, o2};
@@ -273,23 +289,6 @@ __device__ __forceinline__ void apply_tile(const unsigned char *tab, const Scrat
                 const float d0 = o0 - (float)g0, d1 = o1 - (float)g1, d2 = o2 - (float)g2;
                 e = fmaf(d0, d0, e); e = fmaf(d1, d1, e); e = fmaf(d2, d2, e);
             }
-        }
-    } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int32_t iy = (int32_t)slot[(3 * q) * kWave + lane], ix = (int32_t)slot[(3 * q + 1) * kWave + lane], iz = (int32_t)slot[(3 * q + 2) * kWave + lane];
-            // fy' = sL fy + cy ; fx' = fy' + sa (fx - fy) + ca ; fz' = fy' - sb (fy - fz) - cb   (the 2^-30 of the parked words sits in sLs, sas, sbs)
-            const double gy = fma(sLs, (double)iy, c.cy);
-            const double gx = gy + fma(sas, (double)ix, c.ca);
-            const double gz = gy - fma(sbs, (double)iz, c.cb);
-            float r, g, b;
-            lut::f_to_rgb_clip(tab, gx, gy, gz, r, g, b);
-            store_pixel<T>(out_tile, lane, q, r, g, b);
-            if (HAS_GT) {
-                const float d0 = r - gt_of(3 * q), d1 = g - gt_of(3 * q + 1), d2 = b - gt_of(3 * q + 2);
-                e = fmaf(d0, d0, e); e = fmaf(d1, d1, e); e = fmaf(d2, d2, e);
-            }
-            CT_RP_PIXEL_FENCE(q);
         }
     }
     if (HAS_GT) sq += (double)e;
@@ -342,7 +341,7 @@ __device__ __forceinline__ void finish_stats(Scratch *sc, int par, int pair, int
         const double var = fma(-s1, m0, s2) / n;
         const double scale = ch == 0 ? 116.0 : (ch == 1 ? 500.0 : 200.0);
         const double mean = ch == 0 ? fma(116.0, k + m0, -16.0) : scale * (k + m0);
-        const double sd = scale * sqrt(var > 0.0 ? var : (var == var ? 0.0 : var));
+        const double sd = scale * var_to_sd(var, kVarFloorF32);
         sc->stat[img][ch] = mean;
         sc->stat[img][3 + ch] = sd;
         if (ch == 0) { sc->stat[img][6] = n; sc->stat[img][7] = 0.0; }
@@ -450,24 +449,21 @@ __global__ __launch_bounds__(kWaves * kWave) void reinhard_persist_kernel(const 
     if (sizeof(T) == 1 && threadIdx.x < 256) sc->lut255[threadIdx.x] = (float)threadIdx.x / 255.0f;     // IEEE division: the reference's .float() / 255
     __syncthreads();
     if (sizeof(T) == 1 && threadIdx.x < 256) {                   // exactly what the float32 kernel computes for the value k / 255
-        sc->lin255[threadIdx.x] = lut::expand(tab, sc->lut255[threadIdx.x]);
-        sc->lin255f[threadIdx.x] = lut::expand32_a(tab, sc->lut255[threadIdx.x]);
+        sc->lin255f[threadIdx.x] = lut::expand(tab, sc->lut255[threadIdx.x]);
     }
     if (threadIdx.x < 2 * B) {
         // pivot of the shifted sums: pixel 0 of the image in the cube-root domain, on a 2^-10 grid (ct_reinhard.h / linear.hip)
-        float fx = 0.5f, fy = 0.5f, fz = 0.5f;
+        float fy = 0.5f, dxy = 0.0f, dyz = 0.0f;
         if (piv_thread && max(max(__float_as_uint(p0[0]), __float_as_uint(p0[1])), __float_as_uint(p0[2])) <= lut::kOneBits) {
-            double dx, dy, dz;
-            lut::rgb_to_f(tab, p0[0], p0[1], p0[2], dx, dy, dz);
-            fx = (float)dx; fy = (float)dy; fz = (float)dz;
+            lut::rgb_to_f_stats(tab, p0[0], p0[1], p0[2], fy, dxy, dyz);
         }
         sc->piv[threadIdx.x][0] = rintf(fy * 1024.0f) * (1.0f / 1024.0f);
-        sc->piv[threadIdx.x][1] = rintf((fx - fy) * 1024.0f) * (1.0f / 1024.0f);
-        sc->piv[threadIdx.x][2] = rintf((fy - fz) * 1024.0f) * (1.0f / 1024.0f);
+        sc->piv[threadIdx.x][1] = rintf(dxy * 1024.0f) * (1.0f / 1024.0f);
+        sc->piv[threadIdx.x][2] = rintf(dyz * 1024.0f) * (1.0f / 1024.0f);
     }
     __syncthreads();
 
-    uint32_t rawmask0 = 0, rawmask1 = 0;     // per pair parity, bit k: tile k of this wave was parked as raw pixels
+    uint32_t rawmask0 = 0, rawmask1 = 0;     // per pair parity, bit k: tile k of this wave takes the exact code in A
 #ifdef CT_RP_STAMPS          // diagnostic build only: where a stage's time goes (never timed, never shipped)
 #define CT_RP_STAMP(slot) do { if (a.stamps && lane == 0 && (w == 0 || w == kWaves - 1)) \
         a.stamps[(((size_t)g * 2 + (w ? 1 : 0)) * n_stages + st) * 4 + (slot)] = realtime(); } while (0)
@@ -624,9 +620,8 @@ __global__ __launch_bounds__(kWaves * kWave) void reinhard_persist_kernel(const 
         c.sL = uniform_f64(sc->coef[par][0]); c.sa = uniform_f64(sc->coef[par][1]); c.sb = uniform_f64(sc->coef[par][2]);
         c.cy = uniform_f64(sc->coef[par][3]); c.ca = uniform_f64(sc->coef[par][4]); c.cb = uniform_f64(sc->coef[par][5]);
         if (rc == 2) { c.sL = c.sa = c.sb = c.cy = c.ca = c.cb = __longlong_as_double(0x7ff8000000000000ll); }
-        const double cmax = fmax(fmax(fmax(fabs(c.sL), fabs(c.sa)), fmax(fabs(c.sb), fabs(c.cy))), fmax(fabs(c.ca), fabs(c.cb)));
-        const bool coef_bad = !(cmax < 1e6);
-        const double sLs = c.sL * 0x1p-30, sas = c.sa * 0x1p-30, sbs = c.sb * 0x1p-30;
+        const bool coef_bad = !reinhard_coef_fast(c);
+        const float cf[6] = {(float)c.sL, (float)c.sa, (float)c.sb, (float)c.cy, (float)c.ca, (float)c.cb};
         double sq = 0.0;
         const uint32_t rawmask = par ? rawmask1 : rawmask0;
         for (int k = 0; k < Kw; ++k) {
@@ -652,7 +647,7 @@ __global__ __launch_bounds__(kWaves * kWave) void reinhard_persist_kernel(const 
                 const void *np = next_load(st, 2 * k + 1);
                 if (np) Tile<T>::load(np, lane, nxt);
             }
-            apply_tile<T, HAS_GT>(tab, sc, slot, raw, coef_bad, c, sLs, sas, sbs, tgt_tile, gt_tile, a.out + off * 3, cur, sq, lane);
+            apply_tile<T, HAS_GT>(tab, sc, slot, raw, coef_bad, c, cf, tgt_tile, gt_tile, a.out + off * 3, cur, sq, lane);
             if (HAS_GT) cur = nxt;
         }
         if ((int)threadIdx.x < tail) {

@@ -15,12 +15,16 @@ from oracle import lab as olab        # noqa: E402
 from oracle import linear as olin     # noqa: E402
 
 LAB_TOL = 1e-4          # the stated gate
-LAB_TIGHT = 2e-5        # what float32 I/O actually achieves in BOTH arithmetic modes (f32 Lab ulp at 100 = 7.6e-6)
-# per Lab arithmetic mode of the float32 entries (include/ct_hip.h: ct_set_lab_mode): statistics / float32 RGB output.
-# "table": look-up tables, float32 statistics sweep (unbiased per-pixel rounding: ~1e-7 on the mean of 2 M pixels, more on
-# the tiny goldens); "exact": float64 with hardware seeds.  float64 images always take the exact path.
-STATS_TOL = {"exact": 1e-9, "table": 2e-6}
-RGB_TOL = {"exact": 1.5e-7, "table": 2.0e-7}
+# per Lab arithmetic mode of the float32 entries (include/ct_hip.h: ct_set_lab_mode): Lab of the result / statistics / float32
+# RGB output.  "table" (default): look-up tables, float32 arithmetic throughout (round 5: csrc/ct_color_lut.h; the precision
+# margin of the old float64-grade path, 2e-5, is spent on instruction count: held to HALF the gate instead); "exact": float64
+# with hardware seeds.  float64 images always take the exact path.
+#   statistics: the float32 sweep's per-pixel roundings are unbiased (~1e-7 on the mean of 2 M pixels), its float32 matrix
+#   weights are not (up to 3e-8 relative each): ~1e-6 in the Lab means;
+#   RGB: a channel that is the small difference of big terms (saturated colours) turns 2e-5 of Lab into 4e-6 of sRGB.
+LAB_TIGHT = {"exact": 2e-5, "table": 5e-5}
+STATS_TOL = {"exact": 1e-9, "table": 3e-6}
+RGB_TOL = {"exact": 1.5e-7, "table": 6e-6}
 
 
 @pytest.fixture(scope="module")
@@ -73,14 +77,14 @@ def test_reinhard_small_vs_reference(golden_dir, lin, hip, case, mode):
     assert out.min() >= 0 and out.max() <= 1
     ref = g[case + "/reinhard"]
     np.testing.assert_allclose(out, ref, rtol=0, atol=RGB_TOL[mode])
-    assert lab_err(out, ref) <= LAB_TIGHT
+    assert lab_err(out, ref) <= LAB_TIGHT[mode]
     # float64 in -> float64 out
     out64 = lin.color_transfer_between_images(t.astype(np.float64), r.astype(np.float64))
     assert out64.dtype == np.float64
     np.testing.assert_allclose(out64, ref, rtol=0, atol=1e-10)
     # Lab probe: the affine-transferred image before lab2rgb (methods/linear.py:38)
     probe = hip.reinhard_apply(dev(t), hip.lab_stats(dev(t)), hip.lab_stats(dev(r)), to_lab=True).cpu().numpy()
-    assert np.abs(probe.astype(np.float64) - g[case + "/reinhard_lab"]).max() <= LAB_TIGHT
+    assert np.abs(probe.astype(np.float64) - g[case + "/reinhard_lab"]).max() <= LAB_TIGHT[mode]
 
 
 @pytest.mark.parametrize("case", ["uniform", "graded"])
@@ -113,7 +117,7 @@ def test_u8_256_vs_reference(golden_dir, lin, mode):
     sl = (slice(None, None, 3), slice(None, None, 3))
     out = lin.color_transfer_between_images(t, r)
     np.testing.assert_allclose(out[sl], g["reinhard_s3"], rtol=0, atol=RGB_TOL[mode])
-    assert lab_err(out[sl], g["reinhard_s3"]) <= LAB_TIGHT
+    assert lab_err(out[sl], g["reinhard_s3"]) <= LAB_TIGHT[mode]
     np.testing.assert_allclose(lin.color_transfer_in_correlated_color_space(t, r)[sl], g["xiao_s3"], rtol=0, atol=1e-9)
     np.testing.assert_allclose(lin.monge_kantorovitch_color_transfer(t, r)[sl], g["mk_MK_s3"], rtol=0, atol=1e-9)
     # uint8 frames go through img_as_float semantics (k/255 in float64)
@@ -130,13 +134,13 @@ def test_1080p_vs_reference_samples(golden_dir, lin, hip, mode):
     assert hashlib.sha256(t.tobytes()).hexdigest() == str(g["target_sha256"])
     idx = g["idx"]
     st = hip.lab_stats(dev(t)).cpu().numpy()[0]
-    tol = 1e-9 if mode == "exact" else 3e-7                       # 2 M pixels: the float32 sweep's rounding noise averages out
+    tol = STATS_TOL[mode]
     np.testing.assert_allclose(st[0:3], g["lab_mean_t"], rtol=0, atol=tol)
     np.testing.assert_allclose(st[3:6], g["lab_std_t"], rtol=0, atol=tol)
     out = lin.color_transfer_between_images(t, r).reshape(-1, 3)[idx]
     np.testing.assert_allclose(out, g["reinhard_samples"], rtol=0, atol=RGB_TOL[mode])
-    assert lab_err(out, g["reinhard_samples"]) <= LAB_TIGHT
-    assert LAB_TIGHT < LAB_TOL
+    assert lab_err(out, g["reinhard_samples"]) <= LAB_TIGHT[mode]
+    assert max(LAB_TIGHT.values()) < LAB_TOL
     out = lin.monge_kantorovitch_color_transfer(t, r).reshape(-1, 3)[idx]
     np.testing.assert_allclose(out, g["mk_MK_samples"], rtol=0, atol=1e-9)
     out = lin.color_transfer_in_correlated_color_space(t, r).reshape(-1, 3)[idx]
@@ -151,7 +155,7 @@ def test_1080p_full_vs_oracle_and_properties(lin, hip, mode):
     out = lin.color_transfer_between_images(t, r)
     ref = olin.color_transfer_between_images(t, r)
     assert np.abs(out - ref).max() <= RGB_TOL[mode]
-    assert lab_err(out, ref) <= LAB_TIGHT
+    assert lab_err(out, ref) <= LAB_TIGHT[mode]
     # property: the transferred Lab image has exactly the reference's Lab mean/std
     td, rd = dev(t), dev(r)
     st, sr = hip.lab_stats(td), hip.lab_stats(rd)
@@ -160,7 +164,7 @@ def test_1080p_full_vs_oracle_and_properties(lin, hip, mode):
     np.testing.assert_allclose(probe.std(axis=0), sr.cpu().numpy()[0, 3:6], rtol=0, atol=1e-5)
     # property: identity when reference == target (up to the Lab toe constants not being exact inverses)
     same = lin.color_transfer_between_images(t, t)
-    assert np.abs(same - t).max() <= 2e-6
+    assert np.abs(same - t).max() <= (2e-6 if mode == "exact" else 8e-6)
     # determinism: bitwise identical on a second run
     assert np.array_equal(out, lin.color_transfer_between_images(t, r))
     # MK property: output covariance == reference covariance, output mean == reference mean
@@ -181,8 +185,7 @@ def test_ragged_sizes_vs_oracle(lin, shape, dtype, mode):
         assert np.isnan(out).all()                   # sigma_t = 0 -> 0 * inf = nan, as in the reference
         return
     ref = olin.color_transfer_between_images(t, r)
-    # a handful of pixels: the table mode's float32 statistics carry their per-pixel rounding (~6e-8 x 500 in a*) undiluted
-    assert np.abs(out - ref).max() <= ((1.5e-7 if mode == "exact" else 4e-7) if dtype == np.float32 else 1e-9)
+    assert np.abs(out - ref).max() <= (RGB_TOL[mode] if dtype == np.float32 else 1e-9)
     mk = lin.monge_kantorovitch_color_transfer(r, r[::-1].copy())
     np.testing.assert_allclose(mk, olin.monge_kantorovitch_color_transfer(r, r[::-1].copy()), rtol=0, atol=1e-9)
 
@@ -212,7 +215,7 @@ def test_noncontiguous_runner_style_input(lin, mode):
     assert not t.flags.c_contiguous
     out = lin.color_transfer_between_images(t, r)
     ref = olin.color_transfer_between_images(t, r)
-    assert np.abs(out - ref).max() <= (1.5e-7 if mode == "exact" else 4e-7)
+    assert np.abs(out - ref).max() <= RGB_TOL[mode]
 
 
 def _special_inputs(h, w):
@@ -234,6 +237,10 @@ def _special_inputs(h, w):
     o[::7, ::5] = 1.5
     o[::11, ::3] = -0.25
     yield "out-of-range", o, u
+    # low-contrast targets: the map's scales multiply the forward transform's error (ct_reinhard.h: kFastScale)
+    yield "scale-1.9", (u * 0.5 + 0.25).astype(np.float32), u
+    yield "scale-3.3", (u * 0.28 + 0.36).astype(np.float32), u
+    yield "scale-6", (u * 0.15 + 0.4).astype(np.float32), u          # above kFastScale: the exact code
 
 
 def _oracle_lab_transfer(t, r):
@@ -248,7 +255,8 @@ def _oracle_lab_transfer(t, r):
 @pytest.mark.parametrize("size", [(1080, 1920), (270, 483)])
 def test_lab_gate_all_branches_vs_oracle(hip, mode, size):
     """The stated gate, every pixel, at the headline size: float32 Lab max-abs <= 1e-4 against the float64 CPU path; held
-    here to 5e-5 on the transferred Lab image AND on Lab of the final RGB, in both arithmetic modes."""
+    here to 5e-5 on the transferred Lab image AND on Lab of the final RGB for affine scales up to 2 (the table mode's forward
+    error grows with the scale: 1e-4 up to kFastScale = 4, the exact code beyond), 2e-5 in the exact mode."""
     worst = {}
     for name, t, r in _special_inputs(*size):
         lab_ref, rgb_ref = _oracle_lab_transfer(t, r)
@@ -265,9 +273,12 @@ def test_lab_gate_all_branches_vs_oracle(hip, mode, size):
     for name, e in worst.items():
         print("   %-13s %.2e | %.2e | %.2e" % ((name,) + e))
     for name, (e_lab, e_rgb, e_lab_rgb) in worst.items():
-        assert e_lab <= 5e-5, (name, e_lab)
-        assert e_lab_rgb <= 5e-5, (name, e_lab_rgb)
-        assert e_rgb <= 3e-7, (name, e_rgb)
+        lab_tol = LAB_TIGHT[mode] if name != "scale-3.3" or mode == "exact" else LAB_TOL
+        assert e_lab <= lab_tol, (name, e_lab)
+        assert e_lab_rgb <= lab_tol, (name, e_lab_rgb)
+        assert e_rgb <= (3e-7 if mode == "exact" else (RGB_TOL[mode] if name != "scale-3.3" else 1e-5)), (name, e_rgb)
+    if mode == "table":
+        assert max(worst["scale-6"][0], worst["scale-6"][2]) <= LAB_TIGHT["exact"]       # took the exact code
 
 
 def test_table_mode_nan_and_degenerate_statistics(hip, lin):
@@ -285,7 +296,7 @@ def test_table_mode_nan_and_degenerate_statistics(hip, lin):
     hip.set_lab_mode("table")
     assert not np.isfinite(res["table"][0]).any() and not np.isfinite(res["exact"][0]).any()
     assert np.isnan(res["table"][1][0, :6]).all() and np.isnan(res["exact"][1][0, :6]).all()
-    assert np.abs(res["table"][2] - res["exact"][2]).max() <= 2e-7
+    assert np.abs(res["table"][2] - res["exact"][2]).max() <= RGB_TOL["table"]
     with pytest.raises(ValueError):
         hip.set_lab_mode("fast")
 
