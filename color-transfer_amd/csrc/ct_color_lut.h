@@ -143,9 +143,40 @@ __device__ __forceinline__ void lin_to_f_stats(const unsigned char *lds, const f
     dyz = fy - fz;
 }
 
+// The same without table F: the statistics sweep is bound by the LDS pipe (a 16-byte look-up per lane costs the CU ~12 cycles,
+// six of them per pixel), not by vector issue, so its three cube roots come from the transcendental unit instead: r ~ v^(-1/3)
+// from v_log_f32 / v_exp_f32 (~5e-7 relative), y0 = v r^2, one correction step in the residual g = y0 r = v r^3 (exact out of
+// one fma): y = y0 (1 + 2/3 (1 - g)), < 8e-8 relative, symmetric.  The linear toe sits behind one test per pixel.
+__device__ __forceinline__ float cbrt_hw(float v) {
+    const float r = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(v) * (-1.0f / 3.0f));
+    const float u = (v * r) * r;
+    const float e = fmaf(-u, r, 1.0f);
+    return fmaf(u * (2.0f / 3.0f), e, u);
+}
+#define CT_ROW0(l, W, O) fmaf(l[kOrd[O][2]], W[2], fmaf(l[kOrd[O][1]], W[1], l[kOrd[O][0]] * W[0]))
+__device__ __forceinline__ void lin_to_f_stats_hw(const float (&l)[3], float &fy, float &dxy, float &dyz) {
+    const float x = CT_ROW0(l, kMX, 0), y = CT_ROW0(l, kMY, 1), z = CT_ROW0(l, kMZ, 2);
+    float fx = cbrt_hw(x);
+    fy = cbrt_hw(y);
+    float fz = cbrt_hw(z);
+    if (__builtin_amdgcn_ballot_w64(fminf(fminf(x, y), z) <= 0.008856f)) {
+        asm volatile("; lab toe" : "+v"(fx));
+        fx = (x > 0.008856f) ? fx : fmaf(7.787f, x, (float)(16.0 / 116.0));
+        fy = (y > 0.008856f) ? fy : fmaf(7.787f, y, (float)(16.0 / 116.0));
+        fz = (z > 0.008856f) ? fz : fmaf(7.787f, z, (float)(16.0 / 116.0));
+    }
+    dxy = fx - fy;
+    dyz = fy - fz;
+}
+__device__ __forceinline__ void rgb_to_f_stats_hw(const unsigned char *lds, float r, float g, float b, float &fy, float &dxy, float &dyz) {
+    const float l[3] = {expand(lds, r), expand(lds, g), expand(lds, b)};
+    lin_to_f_stats_hw(l, fy, dxy, dyz);
+}
+
 // apply: per-pixel accuracy.  Returns true (per lane) when an argument lies within the rounding error of the 0.008856 kink of
 // f(), where the reference's function jumps: the caller redoes the tile with the exact code.
-constexpr uint32_t kFBand = 6;               // float32 ulps of u on either side of the kink (the argument is good to ~2)
+constexpr float kFBandF = 1.2e-8f;           // ~6 float32 ulps of u on either side of the kink (the argument is good to ~2)
+constexpr float kFKinkHi = kFKink + kFBandF;
 __device__ __forceinline__ bool lin_to_f(const unsigned char *lds, const float (&l)[3], float &fy, float &dxy, float &dyz) {
     const float px = CT_ROW_P(l, kMX, 0), py = CT_ROW_P(l, kMY, 1);
     const float ux = CT_ROW_U(l, kMX, 0, px), uy = CT_ROW_U(l, kMY, 1, py);
@@ -160,10 +191,9 @@ __device__ __forceinline__ bool lin_to_f(const unsigned char *lds, const float (
     dyz = (ay - az) + (ry - rz);
     bool near = false;
     const float mn = fminf(fminf(ux, uy), uz);
-    if (__builtin_amdgcn_ballot_w64(__float_as_uint(mn) <= kFKinkBits + kFBand)) {      // some lane of the wave is in the toe
+    if (__builtin_amdgcn_ballot_w64(mn <= kFKinkHi)) {                                   // some lane of the wave is in the toe
         asm volatile("; kink band" : "+v"(dxy));                                        // keeps this a real branch
-        near = ((int)(__float_as_uint(ux) - (kFKinkBits - kFBand) <= 2 * kFBand) | (int)(__float_as_uint(uy) - (kFKinkBits - kFBand) <= 2 * kFBand) |
-                (int)(__float_as_uint(uz) - (kFKinkBits - kFBand) <= 2 * kFBand)) != 0;
+        near = fminf(fminf(fabsf(ux - kFKink), fabsf(uy - kFKink)), fabsf(uz - kFKink)) <= kFBandF;
     }
     return near;
 }
@@ -186,17 +216,21 @@ __device__ __forceinline__ bool f_to_rgb_clip(const unsigned char *lds, float gy
     bool near = false;
     const float mn = fminf(fminf(gx, gy), gz);
     if (__builtin_amdgcn_ballot_w64(mn <= kToeInv + kInvBand)) {
+        // Some lane of the wave is in the linear toe of the inverse (t <= 0.2068966 -> (t - 16/116) / 7.787).  On uniform random
+        // frames that is nearly every wave (4 % of the pixels), so this block is kept short: the cubes are already there in
+        // difference form -- gx^3 = y + ux, gz^3 = y - uz -- and a component on the linear branch is tiny (<= 0.0089), where plain
+        // differences are exact enough.
         asm volatile("; lab toe" : "+v"(y));
-        near = ((int)(fabsf(gx - kToeInv) <= kInvBand) | (int)(fabsf(gy - kToeInv) <= kInvBand) | (int)(fabsf(gz - kToeInv) <= kInvBand)) != 0;
+        near = fminf(fminf(fabsf(gx - kToeInv), fabsf(gy - kToeInv)), fabsf(gz - kToeInv)) <= kInvBand;
         const float gzc = fmaxf(gz, 0.0f);                      // lab2xyz: z < 0 -> 0
-        const bool bx = gx > kToeInv, by = gy > kToeInv, bz = gzc > kToeInv;
-        const float xx = bx ? (gx * gx) * gx : fmaf(gx, kToeA, kToeB);
-        const float yy = by ? y : fmaf(gy, kToeA, kToeB);
-        const float zz = bz ? (gzc * gzc) * gzc : fmaf(gzc, kToeA, kToeB);
-        y = yy;
-        z = zz;
-        ux = (bx && by) ? ux : xx - yy;                          // both cubes: the difference form stays
-        uz = (bz && by) ? uz : yy - zz;
+        const float xl = fmaf(gx, kToeA, kToeB), yl = fmaf(gy, kToeA, kToeB), zl = fmaf(gzc, kToeA, kToeB);
+        const bool bx = gx > kToeInv, by = gy > kToeInv, bz = gz > kToeInv;
+        const float yn = by ? y : yl;
+        const float dyc = y - yn;                               // 0 where gy is on the cube branch
+        ux = bx ? ux + dyc : xl - yn;                           // h(gx) - h(gy)
+        uz = bz ? uz - dyc : yn - zl;                           // h(gy) - h(gz)
+        z = bz ? z : zl;
+        y = yn;
     }
     r = compress_clip(lds, fmaf(ux, kInvR[1], fmaf(uz, kInvR[2], fmaf(y, kInvR[0], kGShift))));
     g = compress_clip(lds, fmaf(ux, kInvG[1], fmaf(uz, kInvG[2], fmaf(y, kInvG[0], kGShift))));

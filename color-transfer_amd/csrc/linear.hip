@@ -290,7 +290,11 @@ __global__ __launch_bounds__(kLutBlock, CT_LUT_WPE_STATS) void lab_moments_lut_k
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float fy, dxy, dyz;
+#ifdef CT_STATS_CBRT_LUT
                 lut::rgb_to_f_stats(tab, c[3 * q], c[3 * q + 1], c[3 * q + 2], fy, dxy, dyz);
+#else
+                lut::rgb_to_f_stats_hw(tab, c[3 * q], c[3 * q + 1], c[3 * q + 2], fy, dxy, dyz);
+#endif
                 const float dx = fy - kf[0], dy = dxy - kf[1], dz = dyz - kf[2];
                 sf[0] += dx; sf[1] += dy; sf[2] += dz;
                 sf[3] = fmaf(dx, dx, sf[3]); sf[4] = fmaf(dy, dy, sf[4]); sf[5] = fmaf(dz, dz, sf[5]);

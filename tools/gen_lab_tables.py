@@ -316,14 +316,16 @@ def inverse(G, K, gy, dx, dz):
     thr = K["toe_inv"]
     toe = np.minimum(np.minimum(gx, gy), gz) <= thr
     if toe.any():
-        def h(t):
-            return np.where(t > thr, ((t * t).astype(f32) * t).astype(f32), fma32(t, K["toe_a"], K["toe_b"]))
+        # the toe block of ct_color_lut.h: gx^3 = y + ux and gz^3 = y - uz are already there; linear-branch components are tiny
         gzc = np.maximum(gz, f32(0))                                                  # lab2xyz: z < 0 -> 0
-        xx, yy, zz = h(gx), h(gy), h(gzc)
-        y = np.where(toe, yy, y)
-        z = np.where(toe, zz, z)
-        ux = np.where(toe & ~((gx > thr) & (gy > thr)), (xx - yy).astype(f32), ux)
-        uz = np.where(toe & ~((gzc > thr) & (gy > thr)), (yy - zz).astype(f32), uz)
+        xl, yl, zl = fma32(gx, K["toe_a"], K["toe_b"]), fma32(gy, K["toe_a"], K["toe_b"]), fma32(gzc, K["toe_a"], K["toe_b"])
+        bx, by, bz = gx > thr, gy > thr, gz > thr
+        yn = np.where(by, y, yl)
+        dyc = (y - yn).astype(f32)
+        ux = np.where(toe, np.where(bx, (ux + dyc).astype(f32), (xl - yn).astype(f32)), ux)
+        uz = np.where(toe, np.where(bz, (uz - dyc).astype(f32), (yn - zl).astype(f32)), uz)
+        z = np.where(toe, np.where(bz, z, zl), z)
+        y = np.where(toe, yn, y)
     out = []
     for cf, base in ((K["inv_r"], y), (K["inv_g"], y), (K["inv_b"], z)):
         w = fma32(ux, cf[1], fma32(uz, cf[2], fma32(base, cf[0], G["c1"])))
