@@ -26,6 +26,8 @@ constexpr int kSpTW = 32;     // output columns per workgroup (= MFMA N)
 constexpr int kSpKC = 16;     // input channels per stage (= MFMA K)
 constexpr int kSpCUs = 256;
 constexpr int kSkErrWord = 1000;   // stream-K scratch: 32-bit word (of the 1024 flag words) counting consumers that gave up waiting
+// sticky per-device status (ct_device_status bit 1): some stream-K consumer gave up since the last clear
+__device__ unsigned g_sk_status;
 
 // LDS-DMA: 64 lanes x 16 bytes from global straight into LDS at lds_addr + 16 * lane (no registers).  Issued through
 // inline asm on purpose: behind the builtin the compiler puts an s_waitcnt vmcnt(0) in front of every later LDS read
@@ -542,7 +544,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
                     while (!(seen = __hip_atomic_load(a.sk_flags + (blockIdx.x - 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) &&
                            __builtin_amdgcn_s_memrealtime() - t0 < 100000000ull)
                         __builtin_amdgcn_s_sleep(4);
-                    if (!seen) (void)__hip_atomic_fetch_add(a.sk_flags + kSkErrWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!seen) {
+                        (void)__hip_atomic_fetch_add(a.sk_flags + kSkErrWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        (void)__hip_atomic_fetch_or(&g_sk_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                     (void)__hip_atomic_exchange(a.sk_flags + (blockIdx.x - 8), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
                 }
                 __syncthreads();
@@ -810,6 +815,17 @@ int conv_split(const ConvArgs &a, int N, int kh, int kw, bool gen, hipStream_t s
         if (kh == 1 && kw == 1) return launch_split<1, 1, false>(a, N, s);
     }
     return 1;
+}
+
+// sticky status of the current device: 1 = a stream-K consumer gave up waiting for its producer since the last clear (-1: unreadable)
+int conv_split_read_status(bool clear) {
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_sk_status), sizeof(v), 0, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    if (clear && v != 0) {
+        const unsigned z = 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sk_status), &z, sizeof(z), 0, hipMemcpyHostToDevice);
+    }
+    return (int)(v & 1u);
 }
 
 }  // namespace ct

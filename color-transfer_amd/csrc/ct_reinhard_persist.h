@@ -24,6 +24,10 @@ template <typename T>
 int launch(const T *target, const T *reference, const T *gt, float *out, double *psnr_out, int64_t n_pixels, int batch,
            double *stats_out, void *ws, size_t ws_bytes, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);
 
+// sticky status of the current device (bit 0: a bounded spin of some persistent launch gave up since the last clear); -1 = the
+// device could not be read.  Blocks the calling thread for one 4-byte copy; does not wait for running work.
+int read_status(bool clear);
+
 // first word of the workspace after a launch: 0 = ok, otherwise a bounded spin gave up (a workgroup of the grid was not
 // resident); the results of that call are NaN
 constexpr int kErrWord = 0;

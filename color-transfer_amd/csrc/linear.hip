@@ -20,6 +20,7 @@
 #include "ct_reinhard_persist.h"
 
 namespace ct {
+int conv_split_read_status(bool clear);      // conv_split.hip
 
 constexpr int kPartialStride = 12;  // doubles per workgroup partial (6 used for Lab, 9 for RGB cov)
 constexpr int kPivotStride = 4;
@@ -1049,6 +1050,12 @@ static int reinhard_persist_entry(const T *target, const T *reference, const T *
 extern "C" {
 
 int ct_abi_version(void) { return CT_ABI_VERSION; }
+
+int ct_device_status(int clear) {
+    const int a = ct::rp::read_status(clear != 0), b = ct::conv_split_read_status(clear != 0);
+    if (a < 0 || b < 0) return -1;
+    return a | (b << 1);
+}
 
 int ct_set_lab_mode(int mode) {
     if (mode != CT_LAB_TABLE && mode != CT_LAB_EXACT) return CT_E_BADARG;

@@ -31,6 +31,9 @@
 //
 // Determinism: tile -> workgroup -> wave -> lane is a static map, the per-wave trees have a fixed shape, the cross-workgroup
 // sum is exact integer arithmetic.  Results do not depend on the number of pairs per call.
+#include <atomic>
+#include <mutex>
+
 #include "ct_reinhard.h"
 #include "ct_reinhard_persist.h"
 
@@ -115,6 +118,14 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
 }
 __device__ __forceinline__ uint64_t realtime() { return __builtin_amdgcn_s_memrealtime(); }     // 100 MHz
 constexpr uint64_t kSpinTicks = 200000000ull;                    // 2 s
+// Sticky per-device status (one copy of this variable per device: the code object is loaded on each): set when a bounded spin
+// gives up, never cleared by a launch; ct_device_status() reads (and optionally clears) it.  The per-call error word in the
+// workspace turns that call's PSNR records into NaN without any synchronisation (psnr_finish_persist_kernel).
+__device__ unsigned g_status;
+__device__ __forceinline__ void give_up(unsigned *err) {
+    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)__hip_atomic_fetch_or(&g_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // ---- tile I/O per input type -------------------------------------------------------------------------------------------------
 // float32: lane l holds pixels l, l+64, l+128, l+192 of the tile (ct_reinhard.h: one 12-byte access per pixel, 768 contiguous bytes
@@ -311,7 +322,7 @@ __device__ __forceinline__ int collect(const unsigned long long *rec, int nwg, i
         }
         __threadfence_block();
         if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
-        if (realtime() - t0 > kSpinTicks) { if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 2; }
+        if (realtime() - t0 > kSpinTicks) { if (lane == 0) give_up(err); return 2; }
         __builtin_amdgcn_s_sleep(8);
     }
     unsigned long long val = 0, inv = 0;
@@ -567,6 +578,7 @@ __global__ __launch_bounds__(kWaves * kWave) void reinhard_persist_kernel(const 
         // barrier (the SIMD arbitrates by age) starts the next sweep instead.  Safe without further guards: a wave can only pass
         // A(p) once EVERY wave of the grid has published S(p), so no per-parity LDS word of pair p is rewritten (by S(p+2) / A(p+2))
         // before all its readers are through.
+        bool timed_out = false;
         {
             unsigned tk = 0;
             if (lane == 0) tk = atomicAdd(&sc->ticket[par], 1u);
@@ -582,10 +594,18 @@ __global__ __launch_bounds__(kWaves * kWave) void reinhard_persist_kernel(const 
                 CT_RP_STAMP(1);
             }
             if (tk == kWaves - 1 && lane == 0) sc->ticket[par] = 0;                  // every wave is here: free for A(p + 2)
-            while (__hip_atomic_load(&sc->ready[par], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (unsigned)(p + 1)) __builtin_amdgcn_s_sleep(8);
+            // bounded like every other spin of this kernel (the collecting wave gives up after kSpinTicks itself and then publishes
+            // rc = 2: this bound is a second line of defence, 2 x kSpinTicks)
+            bool ready_ok = true;
+            const uint64_t tw = realtime();
+            while (__hip_atomic_load(&sc->ready[par], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (unsigned)(p + 1)) {
+                if (realtime() - tw > 2 * kSpinTicks) { ready_ok = false; if (lane == 0) give_up(a.err); break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (!ready_ok) timed_out = true;
         }
         CT_RP_STAMP(2);
-        const int rc = sc->flag[par];
+        const int rc = timed_out ? 2 : sc->flag[par];
         if (rc == 1) {
             // some workgroup's sums did not fit the integer format (non-finite or huge values): combine the float64 partials
             // of the slab in a fixed order -- 8 interleaved chains per moment, then in chain order (linear.hip's prologue)
@@ -598,7 +618,8 @@ __global__ __launch_bounds__(kWaves * kWave) void reinhard_persist_kernel(const 
                         want = (unsigned long long)((nwg - lane + kShards - 1) / kShards);
                         x = __hip_atomic_load(a.rec + ((size_t)p * kShards + lane) * kRecWords + kSlabWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
-                    if (__builtin_amdgcn_ballot_w64(x != want) == 0 || realtime() - t0 > kSpinTicks) break;
+                    if (__builtin_amdgcn_ballot_w64(x != want) == 0) break;
+                    if (realtime() - t0 > kSpinTicks) { if (lane == 0) give_up(a.err); break; }
                     __builtin_amdgcn_s_sleep(8);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -675,33 +696,50 @@ __global__ __launch_bounds__(kWaves * kWave) void reinhard_persist_kernel(const 
 }
 
 // fixed-order finish of the per-wave squared-error partials -> {mse, PSNR} per frame (piq.psnr semantics, methods/__init__.py:32)
-__global__ __launch_bounds__(256) void psnr_finish_persist_kernel(const double *__restrict__ sq, int n_parts, int64_t n_elems, double *__restrict__ out) {
+__global__ __launch_bounds__(256) void psnr_finish_persist_kernel(const double *__restrict__ sq, int n_parts, int64_t n_elems, double *__restrict__ out,
+                                                                  const unsigned *__restrict__ err) {
     __shared__ double lds[4];
     double s[1] = {0.0};
     for (int i = threadIdx.x; i < n_parts; i += 256) s[0] += sq[(size_t)blockIdx.x * n_parts + i];
     block_sum<1>(s, lds);
     if (threadIdx.x == 0) {
-        const double mse = s[0] / (double)n_elems;
+        double mse = s[0] / (double)n_elems;
+        if (*err != 0u) mse = __longlong_as_double(0x7ff8000000000000ll);       // a spin of the launch gave up: its frames are NaN, so is the metric
         out[blockIdx.x * 2] = mse;
-        out[blockIdx.x * 2 + 1] = 10.0 * log10(1.0 / (mse > 1e-300 ? mse : 1e-300));
+        out[blockIdx.x * 2 + 1] = 10.0 * log10(1.0 / (mse > 1e-300 ? mse : (mse == mse ? 1e-300 : mse)));
     }
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------------
+constexpr int kMaxDevices = 64;
+constexpr int kMaxGrid = 63 * kShards;            // the arrival / invalid counts of a shard record are 6 bits wide
+static int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    return dev >= 0 && dev < kMaxDevices ? dev : 0;
+}
+// workgroups of the launch = CUs of the CURRENT device (cached per device), or CT_HIP_PERSIST_WGS (tuning / a device with
+// masked CUs); 0 = this device cannot take the launch (more workgroups than the hand-off's count fields hold)
 static int grid_size() {
-    static int n = [] {
-        const char *e = getenv("CT_HIP_PERSIST_WGS");          // tuning / a device with masked CUs
-        if (e && atoi(e) > 0) return atoi(e);
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    static std::atomic<int> cache[kMaxDevices];
+    const int dev = current_device();
+    int n = cache[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         (void)hipGetLastError();
-        return cus > 0 ? cus : 256;
-    }();
-    return n;
+        n = cus > 0 ? cus : 256;
+        const char *e = getenv("CT_HIP_PERSIST_WGS");
+        if (e && atoi(e) > 0 && atoi(e) <= n) n = atoi(e);      // never more workgroups than CUs: each needs a CU's LDS to itself
+        if (n > kMaxGrid) n = -1;
+        cache[dev].store(n, std::memory_order_relaxed);
+    }
+    return n > 0 ? n : 0;
 }
 static int slots_for(int64_t n_pixels) {
     const int64_t tiles = n_pixels / kTilePixels;
     const int g = grid_size();
+    if (g <= 0) return kMaxSlots + 1;              // not eligible on this device
     return (int)((tiles + g - 1) / g);
 }
 
@@ -744,11 +782,34 @@ int launch(const T *target, const T *reference, const T *gt, float *out, double 
     // no spills) measured 28.5 - 35.9 k pairs/s against 34.2 - 34.5 k on float32 frames and is not instantiated.
     constexpr int waves = kMaxWaves;
     void (*kern)(const Args) = gt ? reinhard_persist_kernel<T, true, kMaxWaves> : reinhard_persist_kernel<T, false, kMaxWaves>;
-    static bool attr_done[2] = {false, false};                   // per instantiation of this template (T) x gt
-    if (!attr_done[gt ? 1 : 0]) {
+    // function attributes are per device: cached per (device, instantiation of this template (T) x gt)
+    static std::atomic<bool> attr_done[kMaxDevices][2];
+    const int dev = current_device();
+    if (!attr_done[dev][gt ? 1 : 0].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax);
         if (e != hipSuccess) return (int)e;
-        attr_done[gt ? 1 : 0] = true;
+        attr_done[dev][gt ? 1 : 0].store(true, std::memory_order_release);
+    }
+    // Two persistent launches must not share the GPU: each needs every one of its workgroups resident (one per CU, the CU's LDS to
+    // itself), so a second one on another stream would leave both with workgroups that cannot start until the other ends -- a
+    // deadlock only the bounded spins break (2 s, NaN results).  Launches of one device are therefore chained GPU-side through an
+    // event: a launch on another stream waits for the previous one to finish.  (Not inside a stream capture: a captured graph
+    // holds one launch chain of its own stream, and an event from outside the capture cannot be waited on there.)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &cap);
+    (void)hipGetLastError();
+    const bool chain = cap == hipStreamCaptureStatusNone;
+    static std::mutex chain_mutex;
+    static hipEvent_t chain_event[kMaxDevices];
+    static hipStream_t chain_stream[kMaxDevices];
+    std::unique_lock<std::mutex> chain_lock(chain_mutex, std::defer_lock);
+    if (chain) {
+        chain_lock.lock();
+        if (chain_event[dev] == nullptr) {
+            if (hipEventCreateWithFlags(&chain_event[dev], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); chain_event[dev] = nullptr; }
+        } else if (chain_stream[dev] != stream) {
+            (void)hipStreamWaitEvent(stream, chain_event[dev], 0);
+        }
     }
     for (int b0 = 0; b0 < batch; b0 += kMaxPairs) {
         const int b = batch - b0 < kMaxPairs ? batch - b0 : kMaxPairs;
@@ -779,11 +840,26 @@ int launch(const T *target, const T *reference, const T *gt, float *out, double 
         if (ev_stop && b0 + b >= batch) (void)hipEventRecord(ev_stop, stream);
         if (gt) {
             hipLaunchKernelGGL(psnr_finish_persist_kernel, dim3(b), dim3(256), 0, stream, (const double *)a.sq, g * kMaxWaves, n_pixels * 3,
-                               psnr_out + (size_t)b0 * 2);
+                               psnr_out + (size_t)b0 * 2, (const unsigned *)a.err);
             CT_CHECK_LAUNCH();
         }
     }
+    if (chain && chain_event[dev] != nullptr) {
+        (void)hipEventRecord(chain_event[dev], stream);
+        chain_stream[dev] = stream;
+    }
     return CT_OK;
+}
+
+// sticky status of the current device: bit 0 = a bounded spin of a persistent launch gave up since the last clear
+int read_status(bool clear) {
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_status), sizeof(v), 0, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    if (clear && v != 0) {
+        const unsigned z = 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_status), &z, sizeof(z), 0, hipMemcpyHostToDevice);
+    }
+    return (int)(v & 1u);
 }
 
 template int launch<float>(const float *, const float *, const float *, float *, double *, int64_t, int, double *, void *, size_t, hipStream_t,

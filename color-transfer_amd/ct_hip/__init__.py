@@ -11,7 +11,6 @@ GPU raises.
 import ctypes
 import os
 import threading
-import weakref
 import numpy as np
 
 import torch
@@ -19,7 +18,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CT_HIP_LIB") or os.path.join(_HERE, "libct_hip.so")   # CT_HIP_LIB: tuning builds only
 
-CT_ABI_VERSION = 6            # include/ct_hip.h: CT_ABI_VERSION; lib() refuses any other library
+CT_ABI_VERSION = 7            # include/ct_hip.h: CT_ABI_VERSION; lib() refuses any other library
 CT_LAB_STATS_STRIDE = 8
 CT_RGB_STATS_STRIDE = 16
 CT_WS_LAB_STATS, CT_WS_RGB_MEANCOV, CT_WS_REINHARD, CT_WS_IDT, CT_WS_REINHARD_PSNR, CT_WS_REINHARD_PERSIST = 0, 1, 2, 3, 4, 5
@@ -46,6 +45,7 @@ SIGNATURES = {
     "ct_reinhard_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
     "ct_reinhard_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
     "ct_reinhard_psnr_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
+    "ct_device_status": (_c_int, [_c_int]),
     "ct_reinhard_persist_supported": (_c_int, [_c_i64]),
     "ct_reinhard_takes_persist": (_c_int, [_c_i64]),
     "ct_reinhard_persist_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_sz, _c_p]),
@@ -315,6 +315,18 @@ def reinhard_psnr(target, reference, gt, out=None, psnr_out=None):
     check(lib().ct_reinhard_psnr_f32(_ptr(x), _ptr(r), _ptr(g), _ptr(out), _ptr(psnr_out), n, B, ctypes.c_void_p(0), _ptr(ws), ws.numel(),
                                      _stream()))
     return out.view(target.shape), psnr_out
+
+
+def device_status(clear=False, sync=True):
+    """Sticky status bits of the current device (include/ct_hip.h: ct_device_status): 0 = all well; bit 0 = a persistent Reinhard
+    launch gave up a bounded spin (its frames and PSNR records are NaN), bit 1 = a stream-K convolution gave up.  For loops that
+    never synchronise per call: check once at the end (utils/sharding.gather_frame_metrics does)."""
+    if sync:
+        torch.cuda.synchronize()
+    v = lib().ct_device_status(1 if clear else 0)
+    if v < 0:
+        raise CtHipError("ct_device_status: the device could not be read")
+    return v
 
 
 def reinhard_persist_supported(n_pixels):
@@ -724,15 +736,29 @@ def conv_stream_k_state(device=None):
 
 def _conv_scratch(device):
     """The stream-K scratch of the tile convolution for the current stream (include/ct_hip.h: all zero before its first use, then
-    owned by the launches of one stream, which leave its flag words zero again)."""
+    owned by the launches of one stream, which leave its flag words zero again).  None while the stream is being captured and
+    no scratch exists for it yet: an allocation made inside a capture belongs to that graph's private pool (its zero fill is a
+    node of that graph only), so a later graph on the same capture stream would share memory the allocator may already have
+    handed out again -- such launches run without stream-K instead (every workgroup computes whole units, same results)."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    need = lib().ct_conv_split_scratch_bytes()
     with _lock:
         buf = _sk_cache.get(key)
         if buf is None:
-            buf = torch.zeros(need, dtype=torch.uint8, device=device)
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            buf = torch.zeros(lib().ct_conv_split_scratch_bytes(), dtype=torch.uint8, device=device)
             _sk_cache[key] = buf
     return buf
+
+
+def conv_scratch_prepare(device=None, stream=None):
+    """Create the stream-K scratch of `stream` (default: the current one) OUTSIDE any capture, e.g. for the stream a
+    torch.cuda.graph() block is about to capture on, so that the captured convolutions keep stream-K."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    if stream is None:
+        return _conv_scratch(device)
+    with torch.cuda.stream(stream):
+        return _conv_scratch(device)
 
 
 def _conv_split(x, split, cout, kh, kw, act, residual, clamp, out, x2=None, x3=None, res_pre=False, post=None):
@@ -944,26 +970,24 @@ def pack_gconv_weight(weight, bias):
     return wp, b
 
 
-_s2d_last = [None, None]                          # (key, tensor): the two stride-2 convolutions of a residual block read one input
-
-
 def space_to_depth2(x):
-    """[n, c, h, w] -> [n, 4c, h/2, w/2], channel (2 sy + sx) c + ch = x[:, ch, sy::2, sx::2] (ct_space_to_depth2_f32)"""
+    """[n, c, h, w] -> [n, 4c, h/2, w/2], channel (2 sy + sx) c + ch = x[:, ch, sy::2, sx::2] (ct_space_to_depth2_f32).
+    No cache here (round 4 kept the last image keyed on the tensor's identity and `_version`: inference tensors have no version
+    counter, and writers that go through raw pointers -- this library's own out= entries -- do not bump it): a caller whose two
+    stride-2 convolutions read one input makes the image once and hands it to both (gconv2d(..., s2d=...))."""
     if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4 or not x[0].is_contiguous():
         raise CtHipError("space_to_depth2 needs a float32 CUDA tensor [n, c, h, w] with dense images (no CPU path)")
     _check_device(x)
     n, c, h, w = x.shape
-    # the SAME tensor object, unchanged, on the same stream (an address can be reused by another tensor: identity, not data_ptr)
-    hit = _s2d_last[0]
-    stream = torch.cuda.current_stream(x.device).cuda_stream
-    capturing = torch.cuda.is_current_stream_capturing()      # a graph must contain the kernel that makes what its convolutions read
-    if not capturing and hit is not None and hit[0]() is x and hit[1] == (x._version, stream):
-        return _s2d_last[1]
     out = torch.empty((n, 4 * c, h // 2, w // 2), dtype=torch.float32, device=x.device)
     check(lib().ct_space_to_depth2_f32(_ptr(x), _ptr(out), n, c, h, w, _nchw_bstride(x), _stream()))
-    if not capturing:
-        _s2d_last[0], _s2d_last[1] = (weakref.ref(x), (x._version, stream)), out
     return out
+
+
+def s2d_ok(x):
+    """True when a stride-2 3x3 'same' / 1x1 convolution of x can take the tile kernel over space_to_depth2(x) (fp16 form)"""
+    return (_conv_mode == "split" and _ws16 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[2] % 2 == 0 and
+            x.shape[3] % 8 == 0 and x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0 and x[0].is_contiguous())
 
 
 def _split_s2d(wp):
@@ -984,8 +1008,8 @@ def _split_s2d(wp):
     return hit[1]
 
 
-def gconv2d(x, wp, bias, cout, ksize, stride=1, padding=0, act=ACT_NONE, out=None, x2=None, residual=None, addend=None, post=None):
-    """x2: optional second input tensor whose channels follow x's (torch.cat([x, x2], 1) without the copy when the
+def gconv2d(x, wp, bias, cout, ksize, stride=1, padding=0, act=ACT_NONE, out=None, x2=None, residual=None, addend=None, post=None, s2d=None):
+    """s2d: space_to_depth2(x) made by the caller (stride-2 convolutions that share their input); x2: optional second input tensor whose channels follow x's (torch.cat([x, x2], 1) without the copy when the
     split-bf16 kernel takes the convolution; otherwise the concatenation is materialised here).  residual: added to the
     result (act must be ACT_NONE: MBConvBlock's identity skip).  addend: a tensor of the output's shape added BEFORE the
     activation (a pre-computed part of the convolution); split kernel only -- CtHipError otherwise.  post (with addend, fp16 form):
@@ -1025,11 +1049,13 @@ def gconv2d(x, wp, bias, cout, ksize, stride=1, padding=0, act=ACT_NONE, out=Non
         out = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device)
     split = getattr(wp, "_ct_split", None)
     # stride 2, 3x3 "same" or 1x1: the MFMA tile kernel over the space-to-depth image of x (fp16 form)
-    if (stride == 2 and _conv_mode == "split" and _ws16 and split is not None and bias is not None and residual is None and cout > 4 and
-            h % 2 == 0 and w % 8 == 0 and x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0 and x[0].is_contiguous() and
+    if (stride == 2 and split is not None and bias is not None and residual is None and cout > 4 and s2d_ok(x) and
             out.data_ptr() % 16 == 0 and out.stride(0) % 4 == 0 and
             (((kh, kw, ph, pw) == (3, 3, 1, 1) and hasattr(wp, "_ct_src")) or (kh, kw, ph, pw) == (1, 1, 0, 0))):
-        s2d = space_to_depth2(x)
+        if s2d is None:
+            s2d = space_to_depth2(x)
+        elif s2d.shape != (n, 4 * cin, h // 2, w // 2) or s2d.dtype != torch.float32 or not s2d.is_contiguous():
+            raise CtHipError("gconv2d: s2d must be space_to_depth2(x)")
         if kh == 1:
             return _conv_split(s2d[:, :cin], split, cout, 1, 1, act, None, False, out)
         return _conv_split(s2d, _split_s2d(wp), cout, 2, 2, act, None, False, out)

@@ -138,14 +138,15 @@ def _packed_conv(weight, bias):
     return hit[1]
 
 
-def _conv(m, x, act=ACT_NONE, stride=None, padding=None, weight=None, x2=None, out=None):
-    """Conv2d module (or a bare weight) -> ct_gconv2d_f32; x2 = second input whose channels follow x's (no torch.cat)"""
+def _conv(m, x, act=ACT_NONE, stride=None, padding=None, weight=None, x2=None, out=None, s2d=None):
+    """Conv2d module (or a bare weight) -> ct_gconv2d_f32; x2 = second input whose channels follow x's (no torch.cat); s2d =
+    ct_hip.space_to_depth2(x) when several stride-2 convolutions read x"""
     w = m.weight if weight is None else weight
     b = getattr(m, "bias", None) if weight is None else None
     wp, bp = _packed_conv(w, b)
     st = (m.stride[0] if weight is None else 1) if stride is None else stride
     pd = (tuple(m.padding) if weight is None else 1) if padding is None else padding
-    return ct_hip.gconv2d(x, wp, bp, w.shape[0], (w.shape[2], w.shape[3]), st, pd, act=act, x2=x2, out=out)
+    return ct_hip.gconv2d(x, wp, bp, w.shape[0], (w.shape[2], w.shape[3]), st, pd, act=act, x2=x2, out=out, s2d=s2d)
 
 
 def _lin(m, x, act=ACT_NONE, x2=None):
@@ -238,9 +239,11 @@ class GMFlow(nn.Module):
 
     # ---- unimatch/backbone.py:104-120 ----
     def _resblock(self, blk, x):
-        y = ct_hip.instance_norm(_conv(blk.conv1, x), 1)
+        # a down-sampling block's two stride-2 convolutions read one input: its space-to-depth image is made once
+        s2d = ct_hip.space_to_depth2(x) if (blk.downsample is not None and blk.stride == 2 and ct_hip.s2d_ok(x)) else None
+        y = ct_hip.instance_norm(_conv(blk.conv1, x, s2d=s2d), 1)
         y = _conv(blk.conv2, y)
-        skip = x if blk.downsample is None else ct_hip.instance_norm(_conv(blk.downsample[0], x), 0)
+        skip = x if blk.downsample is None else ct_hip.instance_norm(_conv(blk.downsample[0], x, s2d=s2d), 0)
         return ct_hip.instance_norm(y, 2, skip)         # relu(skip + relu(IN(conv2)))
 
     def _backbone(self, x):

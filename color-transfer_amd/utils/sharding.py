@@ -50,6 +50,13 @@ def gather_frame_metrics(local_metrics, n_frames, rank=None, world=None):
         world = dist.get_world_size() if dist.is_initialized() else 1
     if rank is None:
         rank = dist.get_rank() if dist.is_initialized() else 0
+    if local_metrics.is_cuda:
+        # the one place a run that never synchronises per frame looks at the device's sticky status (include/ct_hip.h:
+        # ct_device_status): a persistent launch / stream-K convolution that gave up a bounded spin left NaN / wrong frames
+        import ct_hip
+        status = ct_hip.device_status(clear=True)
+        if status:
+            raise RuntimeError("rank %d: the HIP kernels reported status 0x%x (a launch gave up a bounded spin: results invalid)" % (rank, status))
     n_pad = padded_local_count(n_frames, world)
     n_metrics = local_metrics.shape[1]
     buf = torch.full((n_pad, n_metrics), float("nan"), dtype=local_metrics.dtype, device=local_metrics.device)

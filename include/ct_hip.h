@@ -34,9 +34,10 @@ extern "C" {
 #define CT_E_ALIGN (-3)      /* image base not aligned to its element size */
 
 /* bumped whenever an entry point changes its argument list (2: ct_attention_tokens_f32 gained kv_shift; 3: round 3; 4: ct_conv2d_split_rows_f32, res_pre_act, ct_linear_ws16_f32, layernorm partials, f16 form of ct_conv2d_split*;
- * 5: ct_reinhard_persist_*, ct_reinhard_psnr_u8, CT_WS_REINHARD_PERSIST; 6: ct_conv2d_split_f32 gained scratch / scratch_bytes);
+ * 5: ct_reinhard_persist_*, ct_reinhard_psnr_u8, CT_WS_REINHARD_PERSIST; 6: ct_conv2d_split_f32 gained scratch / scratch_bytes;
+ * 7: ct_device_status);
  * the ctypes binding refuses a library whose ct_abi_version() differs */
-#define CT_ABI_VERSION 6
+#define CT_ABI_VERSION 7
 
 /* doubles per image in a stats record written by ct_lab_stats / ct_rgb_meancov */
 #define CT_LAB_STATS_STRIDE 8  /* mean[3], std[3] (population, ddof 0), n, 0           */
@@ -52,6 +53,16 @@ enum ct_workspace_kind {
 };
 
 int ct_abi_version(void);
+
+/* Sticky status of the CURRENT device, for callers that never synchronise per call (video loops, graphs): a bit mask, 0 = all well.
+ *   bit 0: a bounded spin of a persistent Reinhard launch gave up (a workgroup of its grid never became resident: that call's
+ *          frames and PSNR records are NaN);
+ *   bit 1: a stream-K consumer of ct_conv2d_split_f32 gave up waiting for its producer (that launch's tile is wrong).
+ * Neither can happen while the launch's workgroups are all resident; both are bounded so that a queue never hangs.  clear != 0
+ * resets the bits read.  Blocks the calling thread for two 4-byte copies and does NOT wait for running work: synchronise the
+ * streams of interest first.  Returns -1 when the device cannot be read.  New in ABI 7; the reference has no counterpart
+ * (its CPU path cannot fail this way). */
+int ct_device_status(int clear);
 
 /* Lab arithmetic of the float32 entries (ct_lab_stats_f32, ct_reinhard_*_f32, ct_reinhard_lab_f32):
  *   CT_LAB_TABLE (default)  the power functions of skimage's rgb2lab / lab2rgb (methods/linear.py:25,26,40) are LDS

@@ -331,10 +331,25 @@ def test_conv_split_stream_k_graph_replay_and_busy_gpu(hip):
     wt, b = (rnd(cout, cin, 1, 5) / (cin * 5) ** 0.5).cuda(), rnd(cout).cuda()
     wp, bp = hip.pack_gconv_weight(wt, b)
     out = torch.empty((2, cout, h, w), device="cuda")
-    hip.gconv2d(x, wp, bp, cout, (1, 5), 1, (0, 2), out=out)              # warm: the stream's scratch exists
+    hip.gconv2d(x, wp, bp, cout, (1, 5), 1, (0, 2), out=out)              # warm
     torch.cuda.synchronize()
+    # the scratch of the CAPTURE stream is made before the capture (one allocated inside a capture would live in that
+    # graph's private pool and be shared with later graphs through the binding's cache); without it a captured launch runs
+    # without stream-K
+    cap = torch.cuda.Stream()
+    n_before = len(hip._sk_cache)
+    g0 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g0, stream=cap):
+        hip.gconv2d(x, wp, bp, cout, (1, 5), 1, (0, 2), out=out)
+    assert len(hip._sk_cache) == n_before                                  # nothing was cached from inside the capture
+    g0.replay()
+    torch.cuda.synchronize()
+    whole = hip.gconv2d(x, wp, bp, cout, (1, 5), 1, (0, 2))
+    assert (out - whole).abs().max().item() <= 2e-5                        # whole units instead of shared ones: same bound, other bits
+    del g0
+    assert hip.conv_scratch_prepare(stream=cap) is not None
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with torch.cuda.graph(graph, stream=cap):
         hip.gconv2d(x, wp, bp, cout, (1, 5), 1, (0, 2), out=out)
     for _ in range(3):
         x2 = rnd(2, cin, h, w).cuda()

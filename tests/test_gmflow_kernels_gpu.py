@@ -469,16 +469,16 @@ def test_attention_tiny_sequences(hip, l):
     close(colsum, p6.sum(dim=1), "column sums", atol=5e-5, rtol=1e-4)
 
 
-def test_space_to_depth_and_stride2_cache(hip):
-    """ct_space_to_depth2_f32: channel (2 sy + sx) C + c of the result is x[:, c, sy::2, sx::2]; the binding keeps the image of the
-    last input (the two stride-2 convolutions of a residual block read the same tensor) and notices an in-place change"""
+def test_space_to_depth_and_shared_stride2_input(hip):
+    """ct_space_to_depth2_f32: channel (2 sy + sx) C + c of the result is x[:, c, sy::2, sx::2].  No cache in the binding (ADVICE r04:
+    inference tensors have no version counter, raw-pointer writers do not bump it): a caller whose two stride-2 convolutions read
+    one input passes the image to both (gconv2d(..., s2d=...)) -- same bits as without, also under torch.inference_mode()."""
     x = rnd(2, 5, 12, 24).cuda()
     s2d = hip.space_to_depth2(x)
     assert s2d.shape == (2, 20, 6, 12)
     for sy in range(2):
         for sx in range(2):
             assert torch.equal(s2d[:, (2 * sy + sx) * 5:(2 * sy + sx + 1) * 5], x[:, :, sy::2, sx::2])
-    assert hip.space_to_depth2(x) is s2d
     x.mul_(2.0)
     again = hip.space_to_depth2(x)
     assert again is not s2d and torch.equal(again[:, :5], x[:, :, ::2, ::2])
@@ -486,6 +486,24 @@ def test_space_to_depth_and_stride2_cache(hip):
     assert torch.equal(hip.space_to_depth2(view)[:, 5:10], view[:, :, 0::2, 1::2])
     with pytest.raises(hip.CtHipError):
         hip.space_to_depth2(rnd(1, 4, 7, 24).cuda())
+    # a down-sampling residual block's pair of convolutions (unimatch/backbone.py:9-45) on a shared image
+    cin, cout, h, w = 64, 96, 32, 48
+    xx = rnd(2, cin, h, w).cuda()
+    w3, w1, b1 = (rnd(cout, cin, 3, 3) / 24).cuda(), (rnd(cout, cin, 1, 1) / 8).cuda(), rnd(cout).cuda()
+    p3, p1 = hip.pack_gconv_weight(w3, torch.zeros(cout).cuda()), hip.pack_gconv_weight(w1, b1)
+    assert hip.s2d_ok(xx)
+    ref3, ref1 = hip.gconv2d(xx, p3[0], p3[1], cout, 3, 2, 1), hip.gconv2d(xx, p1[0], p1[1], cout, 1, 2, 0)
+    shared = hip.space_to_depth2(xx)
+    assert torch.equal(hip.gconv2d(xx, p3[0], p3[1], cout, 3, 2, 1, s2d=shared), ref3)
+    assert torch.equal(hip.gconv2d(xx, p1[0], p1[1], cout, 1, 2, 0, s2d=shared), ref1)
+    want = torch.nn.functional.conv2d(xx.double(), w3.double(), None, 2, 1)
+    assert (ref3.double() - want).abs().max().item() < 1e-4
+    with torch.inference_mode():                               # Lightning's test loop (the reference's `utils.cli test`)
+        xi = xx.clone()
+        assert torch.equal(hip.gconv2d(xi, p3[0], p3[1], cout, 3, 2, 1), ref3)
+        assert torch.equal(hip.gconv2d(xi, p1[0], p1[1], cout, 1, 2, 0, s2d=hip.space_to_depth2(xi)), ref1)
+    with pytest.raises(hip.CtHipError):
+        hip.gconv2d(xx, p3[0], p3[1], cout, 3, 2, 1, s2d=shared[:, :8])
 
 
 @pytest.mark.parametrize("kind", ["smooth", "constant", "jump", "random", "outside", "nan"])
@@ -538,12 +556,13 @@ def test_local_corr_softmax_tile_form(hip, b, h, w, r):
 
 
 def test_stride2_conv_in_a_graph_reads_fresh_data(hip):
-    """the cached space-to-depth image is never used inside a capture: a replayed graph convolves what is in its input NOW"""
+    """a captured stride-2 convolution contains the kernel that makes its space-to-depth image: a replayed graph convolves what is in
+    its input NOW"""
     x = rnd(2, 64, 24, 64).cuda()
     wt, b = (rnd(96, 64, 3, 3) / 24).cuda(), rnd(96).cuda()
     wp, bp = hip.pack_gconv_weight(wt, b)
     out = torch.empty((2, 96, 12, 32), device="cuda")
-    hip.gconv2d(x, wp, bp, 96, (3, 3), 2, (1, 1), out=out)               # warm (and fills the cache for this very tensor object)
+    hip.gconv2d(x, wp, bp, 96, (3, 3), 2, (1, 1), out=out)               # warm
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):

@@ -286,3 +286,28 @@ def test_more_pairs_than_one_launch_holds(hip):
         assert torch.equal(s1[0], stats[b]) and torch.equal(s1[1], stats[B + b])
         ref = olin.color_transfer_between_images(t[b], r[b])
         assert np.abs(out[b].cpu().numpy() - ref).max() <= RGB_TOL
+
+
+def test_two_streams_are_chained_and_status_is_clean(hip):
+    """Two persistent launches must not share the GPU (each needs all of its workgroups resident): launches of one device are
+    chained through an event, so calls from two streams run one after the other instead of starving each other until the
+    bounded spins give up.  The device's sticky status stays 0 (include/ct_hip.h: ct_device_status)."""
+    import time
+    rng = np.random.default_rng(31)
+    t, r, g = (dev(rng.random((4, 1080, 1920, 3), dtype=np.float32)) for _ in range(3))
+    want_o, want_p = hip.reinhard_persist(t, r, gt=g, verify=True)
+    want_o, want_p = want_o.clone(), want_p.clone()
+    assert hip.device_status(clear=True) == 0
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        for s in (sa, sb):
+            with torch.cuda.stream(s):
+                outs.append(hip.reinhard_persist(t, r, gt=g))
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 1.0                       # a starved launch would sit in 2 s spins
+    for o, p in outs:
+        assert torch.equal(o, want_o) and torch.equal(p, want_p)
+    assert hip.device_status() == 0
