@@ -42,7 +42,7 @@ ALGO_BYTES_PER_PAIR = 3 * PLANE_F32          # read target, read reference, writ
 HBM_PEAK = 8.0e12                            # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
 BASELINE_METRIC = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
 # arithmetic the headline path computes in, per Lab mode (ct_set_lab_mode)
-DTYPE = {"table": "f32 statistics / f64-grade apply (float32 I/O)",
+DTYPE = {"table": "f32 (float32 I/O; float32 difference forms in both sweeps, float64 only in the per-frame statistics records)",
          "exact": "f64 (float32 I/O, float64 arithmetic)"}
 
 
@@ -76,98 +76,27 @@ def cpu_baseline(n_pairs=4):
                       "median %.3f s/pair; host has %d cores" % (n_pairs, med, os.cpu_count() or 0)}
 
 
-def video_stream(n_frames, dtype, device, rank, world, pool_size=8):
-    """BASELINE.json configs[4] on this rank's share of an n_frames 1080p stereo video (frame f -> rank f % world): every
-    frame triple (target, reference, ground truth) is UPLOADED from pinned host memory (the host buffers hand-over of the
-    drop-in boundary: PCIe is inside this measurement, unlike `value`), corrected by methods.linear.color_transfer_between_images
-    and scored (per-frame PSNR fused); the [frames, 1] table is gathered with one collective at the end.  Uploads run on a copy
-    stream, two uploads ahead of the kernels.  uint8 frames travel four triples per copy (74.6 MB, the size of ONE float32 triple:
-    single 18.7 MB copies reached 47.8 GB/s, float32 triples 53.4) and are corrected four pairs per call by ct_reinhard_psnr_u8,
-    which reads the bytes; float32 frames one triple per copy and call.  The host frames cycle through a pool of `pool_size`
-    distinct pinned chunks (decoding / generating 1000 distinct frames on the host would measure the host)."""
-    import ct_hip
-    from utils import sharding as sh
-    np_dtype = np.uint8 if dtype == "u8" else np.float32
-    chunk = 4 if dtype == "u8" else 1
-    pool = []
-    for i in range(pool_size):
-        rng = np.random.default_rng(4321 + i)
-        trip = rng.integers(0, 256, (3, chunk, H, W, 3), dtype=np.uint8)          # [role][frame of the chunk][H][W][3]
-        if dtype != "u8":
-            trip = trip.astype(np.float32) / np.float32(255)
-        pool.append(torch.from_numpy(np.ascontiguousarray(trip.astype(np_dtype))).pin_memory())
-    mine = sh.frames_of_rank(n_frames, rank, world)
-    n_local = len(mine)
-    n_chunks = (n_local + chunk - 1) // chunk
-    copy_stream = torch.cuda.Stream(device=device)
-    main = torch.cuda.current_stream(device)
-    depth = 3
-    dev_raw = [torch.empty((3, chunk, H, W, 3), dtype=pool[0].dtype, device=device) for _ in range(depth)]
-    uploaded = [torch.cuda.Event() for _ in range(depth)]
-    consumed = [torch.cuda.Event() for _ in range(depth)]
-    out = torch.empty((chunk, H, W, 3), dtype=torch.float32, device=device)
-    rec = torch.zeros((max(n_chunks * chunk, 1), 2), dtype=torch.float64, device=device)
-
-    def frames_of(c):
-        return min(chunk, n_local - c * chunk)
-
-    def upload(c):
-        slot, k = c % depth, frames_of(c)
-        with torch.cuda.stream(copy_stream):
-            if c >= depth:
-                copy_stream.wait_event(consumed[slot])          # the kernels that read this slot's previous chunk are done
-            src = pool[mine[c * chunk] % pool_size]
-            if k == chunk:
-                dev_raw[slot].copy_(src, non_blocking=True)
-            else:                                               # ragged last chunk: only the frames that exist
-                dev_raw[slot][:, :k].copy_(src[:, :k], non_blocking=True)
-            uploaded[slot].record(copy_stream)
-
-    def process(c):
-        slot, k = c % depth, frames_of(c)
-        main.wait_event(uploaded[slot])
-        src = dev_raw[slot]
-        r = rec[c * chunk:c * chunk + k]
-        if dtype == "u8":
-            # ct_reinhard_psnr_u8 reads the bytes: k / 255 (the reference's .float() / 255, utils/data.py:84,106,125) and its gamma
-            # expansion come out of 256-entry tables inside the kernel -- no conversion pass, no torch kernel in the loop
-            ct_hip.reinhard_persist(src[0, :k], src[1, :k], gt=src[2, :k], out=out[:k], psnr_out=r)
-        else:
-            ct_hip.reinhard_psnr(src[0, :k], src[1, :k], src[2, :k], out=out[:k], psnr_out=r)
-        consumed[slot].record(main)
-
-    # initialisation: code objects, clocks, the communicator
-    for c in range(min(depth, n_chunks)):
-        upload(c)
-    for c in range(min(depth, n_chunks)):
-        process(c)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for c in range(min(depth - 1, n_chunks)):
-        upload(c)
-    for c in range(n_chunks):
-        if c + depth - 1 < n_chunks:
-            upload(c + depth - 1)
-        process(c)
-    table = sh.gather_frame_metrics(rec[:n_local, 1:2], n_frames, rank, world)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    bytes_per_frame = 3 * H * W * 3 * pool[0].element_size()
-    return {"frames": n_frames, "host_dtype": dtype, "frames_per_s": n_frames / dt, "ms_per_frame_per_gpu": dt / max(n_local, 1) * 1e3,
-            "h2d_GB_per_s_per_gpu": bytes_per_frame * n_local / dt / 1e9, "h2d_bytes_per_frame": bytes_per_frame,
-            "frames_per_copy_and_call": chunk,
-            "pcie_gen5_x16_GB_per_s": 63.0, "mean_psnr": float(table[:, 0].mean()),
-            "entry": "ct_reinhard_psnr_u8 (persistent launch, reads the bytes)" if dtype == "u8" else "ct_reinhard_psnr_f32",
-            "note": "uploads (3 frames per stereo triple, %d triple(s) per copy) on a copy stream two uploads ahead, %d pair(s) per Reinhard call, "
-                    "PSNR fused, one gather; host frames from a pool of %d pinned chunks" % (chunk, chunk, pool_size)}
+def video_stream(n_frames, rank, world):
+    """BASELINE.json configs[4] through the PRODUCT'S entry point: `utils.cli test --config configs/others.yaml --model.metrics psnr
+    --data.synthetic video_u8 --data.n_frames N` (the reference's way in, utils/cli.py:1-3; methods/__init__.py:18-40).  This
+    rank's share of an n_frames 1080p stereo video (frame f -> rank f % world) arrives as uint8 frames in pinned host memory (the
+    host-buffer hand-over of the drop-in boundary: PCIe is inside this measurement, unlike `value`), four stereo triples per
+    upload on a copy stream two uploads ahead; Runner.test_group corrects and scores four pairs per call
+    (ct_reinhard_psnr_u8 reads the bytes; clamp + PSNR of Runner.test_step fused); ONE gather of the [frames, metrics] table
+    at the end.  Timed by utils.cli.main itself (barrier + synchronize on both sides, max over ranks)."""
+    from utils import cli
+    timing = {}
+    argv = ["test", "--config", os.path.join(PKG, "configs", "others.yaml"), "--model.metrics", "psnr", "--data.data_dir", "null",
+            "--data.synthetic", "video_u8", "--data.n_frames", str(n_frames), "--data.height", str(H), "--data.width", str(W)]
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):        # the CLI prints its means; this program's stdout carries ONE JSON line
+        table = cli.main(argv, timing=timing)
+    dt, n_local = timing["seconds"], timing["frames_local"]
+    return {"frames": n_frames, "host_dtype": "u8", "frames_per_s": n_frames / dt, "ms_per_frame_per_gpu": dt / max(n_local, 1) * 1e3,
+            "h2d_GB_per_s_per_gpu": timing["h2d_bytes"] / dt / 1e9, "h2d_bytes_per_frame": 3 * H * W * 3,
+            "frames_per_copy_and_call": timing["frames_per_call"], "pcie_gen5_x16_GB_per_s": 63.0, "mean_psnr": float(table[:, 0].mean()),
+            "entry": "utils.cli.main(%s) -> Runner.test_group -> ct_reinhard_psnr_u8 (persistent launch, reads the bytes)" % " ".join(argv[3:]),
+            "note": "measured inside utils.cli.main (the product's CLI), not by a loop of bench.py; grouped path: %s" % timing["grouped"]}
 
 
 def main():
@@ -191,12 +120,22 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     from utils.sharding import pin_rank_to_cpus
     pin_rank_to_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))      # one CPU slice per rank, before any GPU call
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # CT_BENCH_DEVICE=cpu: a DRY RUN of this file's multi-rank plumbing on CPU tensors with the gloo backend (tests/test_bench_gloo.py):
+    # process group -> ranks_seen all-reduce -> warm-up gather -> timed steps -> gather -> max-over-ranks -> the JSON line, with a
+    # stub in place of the HIP call.  It measures nothing and says so ("dry_run": true); the product path has no CPU fallback.
+    on_cpu = os.environ.get("CT_BENCH_DEVICE", "cuda") == "cpu"
+    if on_cpu:
+        device = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     ranks_seen = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if on_cpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         assert dist.get_world_size() == args.gpus, "--gpus %d but the communicator has %d ranks" % (args.gpus, dist.get_world_size())
         one = torch.ones(1, dtype=torch.int64, device=device)
         dist.all_reduce(one)                            # counted by the communicator itself, not read from the environment
@@ -223,6 +162,9 @@ def main():
     gathered = torch.empty((world,) + tuple(metrics.shape), dtype=torch.float64, device=device) if world > 1 else None
 
     def step(i):
+        if on_cpu:                                  # dry run: a stand-in that fills this step's rows of the table
+            metrics[i] = torch.tensor(frame_ids, dtype=torch.float64).view(B, 1) + 0.001 * i
+            return
         if psnr_rec is not None:                    # transfer + per-frame PSNR in one fused call (ct_reinhard_psnr_f32)
             ct_hip.reinhard_psnr(tgt, ref, gt, out=out, psnr_out=psnr_rec[i])
             return
@@ -237,14 +179,15 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not on_cpu:
+            torch.cuda.synchronize()
 
     # initialisation, not warm-up: every op of the timed region runs once (code objects load on first launch -- round 2's
     # driver line paid 42 ms for the first launch of a torch copy kernel inside its 50 ms timed region) and the GPU is
     # brought to its sustained clock with INIT_S seconds of the same step; the W warm-up steps follow as the contract says
     step(0)
     if world > 1:
-        dist.all_gather_into_tensor(gathered, metrics)      # warms the communicator
+        dist.all_gather_into_tensor(gathered.flatten(0, 1), metrics)      # warms the communicator (concatenated form: every backend takes it)
     barrier()
     t_init = time.perf_counter()
     init_steps = 1
@@ -252,7 +195,8 @@ def main():
         for _ in range(8):
             step(0)
         init_steps += 8
-        torch.cuda.synchronize()
+        if not on_cpu:
+            torch.cuda.synchronize()
     for i in range(Wm):
         step(i % K)
     barrier()
@@ -260,7 +204,7 @@ def main():
     for i in range(K):
         step(i)
     if world > 1:
-        dist.all_gather_into_tensor(gathered, metrics)      # the per-frame metric gather (RCCL over xGMI)
+        dist.all_gather_into_tensor(gathered.flatten(0, 1), metrics)      # the per-frame metric gather (RCCL over xGMI)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -274,7 +218,7 @@ def main():
     roof = None
     roof_cnn = None
     extra = {}
-    if rank == 0:
+    if rank == 0 and not on_cpu:
         # exact per-kernel durations: the library records HIP events on the launch stream right before / after
         # moments_kernel<float,true> and reinhard_apply_kernel<float,false> of the same fused call that `value` times
         n_prof = min(K, 50)
@@ -521,16 +465,14 @@ def main():
 
     # configs[4] with the uploads inside the measurement: every rank takes part (frame f -> rank f % world)
     n_video = args.video if args.video > 0 else (1000 if (world == 1 and not args.no_extra) else 0)
-    if n_video > 0:
+    if n_video > 0 and not on_cpu:
         del tgt, ref, gt, out
         torch.cuda.empty_cache()
-        vid = {"u8": video_stream(n_video, "u8", device, rank, world)}
-        if world == 1:
-            vid["f32"] = video_stream(max(n_video // 4, 8), "f32", device, rank, world)
+        vid = {"u8": video_stream(n_video, rank, world)}
         if rank == 0:
             extra["video_stream"] = vid
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not on_cpu:
         cpu = cpu_baseline()
 
     if rank == 0:
@@ -541,11 +483,14 @@ def main():
             "source_stamp": source_stamp(),
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE[ct_hip.lab_mode()], "data": "synthetic",
+            **({"dry_run": True, "dry_run_note": "CT_BENCH_DEVICE=cpu: gloo plumbing check with a stub step; `value` is meaningless",
+                "gathered_rows": int(gathered.shape[0] * gathered.shape[1] * gathered.shape[2]) if gathered is not None else int(metrics.shape[0] * metrics.shape[1]),
+                "gathered_checksum": float((gathered if gathered is not None else metrics).sum())} if on_cpu else {}),
             # the other half of BASELINE.json's metric: dcmcs3di forward at 1920x1080 on the same GPU (details: roofline_cnn)
             "value_cnn": roof_cnn["pairs_per_s"] if roof_cnn else None, "unit_cnn": "stereopairs/s (dcmcs3di fwd, 1920x1080)",
             "config": {"workload": "configs[1]: methods.linear.color_transfer_between_images (Reinhard) on "
-                                   "1920x1080 synthetic float32 RGB pairs, HBM-resident; apply sweep float64-grade, "
-                                   "statistics sweep float32 (the reference's own precision for float32 frames); "
+                                   "1920x1080 synthetic float32 RGB pairs, HBM-resident; float32 arithmetic in both sweeps "
+                                   "(difference forms, Lab within 5e-5 of the float64 reference; gate 1e-4); "
                                    "+ per-frame %s against resident ground truth" % (",".join(names) or "no metric"),
                        "pairs_per_step_per_gpu": B, "io_dtype": "float32", "height": H, "width": W,
                        "lab_arithmetic": ct_hip.lab_mode(), "metrics": names,

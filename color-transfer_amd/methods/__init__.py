@@ -47,7 +47,10 @@ METRICS = ("Test PSNR", "Test SSIM", "Test FSIM", "Test iCID")        # what tes
 
 
 class Runner(torch.nn.Module):
-    def __init__(self, func_spec):
+    def __init__(self, func_spec, metrics=None):
+        """func_spec: the reference's only argument (methods/__init__.py:12).  metrics (not in the reference): which of psnr, ssim,
+        fsim, icid test_step computes -- default all four, like the reference; `psnr` alone lets the Reinhard transfer take its
+        fused uint8 entry (test_group)."""
         super().__init__()
         specs = func_spec.split(".")
         module, func = ".".join(specs[:-1]), specs[-1]
@@ -55,6 +58,27 @@ class Runner(torch.nn.Module):
         self.func = getattr(mod, func)
         self.func_cuda = getattr(mod, func + "_cuda", None)
         self.func_spec = func_spec
+        names = ("psnr", "ssim", "fsim", "icid") if metrics is None else tuple(m.strip() for m in (metrics.split(",") if isinstance(metrics, str) else metrics))
+        if not names or any(m not in ("psnr", "ssim", "fsim", "icid") for m in names):
+            raise ValueError("metrics: a subset of psnr, ssim, fsim, icid (got %r)" % (metrics,))
+        self.metrics = names
+        self._out = None
+
+    def takes_groups(self):
+        """True when whole groups of uint8 frames can go through ONE fused call: the Reinhard transfer with PSNR as the only
+        metric (ct_reinhard_psnr_u8 reads the bytes; k / 255 and its gamma expansion come from tables inside the kernel)."""
+        return self.func_spec == "methods.linear.color_transfer_between_images" and self.metrics == ("psnr",)
+
+    def test_group(self, group_u8, psnr_out):
+        """group_u8: device uint8 [3 roles: target, reference, gt][k][H][W][3]; psnr_out: float64 [k, 2] rows of the caller's table,
+        filled with (mse, PSNR) per frame -- Runner.test_step's clamp + piq.psnr (methods/__init__.py:30-32) for k frames in one
+        asynchronous call, nothing else on the stream."""
+        import ct_hip
+        k = group_u8.shape[1]
+        if self._out is None or self._out.shape[1:] != group_u8.shape[2:] or self._out.shape[0] < k or self._out.device != group_u8.device:
+            self._out = torch.empty((max(k, 4),) + tuple(group_u8.shape[2:]), dtype=torch.float32, device=group_u8.device)
+        ct_hip.reinhard_persist(group_u8[0], group_u8[1], gt=group_u8[2], out=self._out[:k], psnr_out=psnr_out)
+        return self._out[:k]
 
     def forward(self, batch):
         target, reference = batch["target"], batch["reference"]
@@ -75,7 +99,9 @@ class Runner(torch.nn.Module):
     def test_step(self, batch, batch_idx=0, dataloader_idx=0):
         result = self(batch).clamp(0, 1)
         gt = batch["gt"].to(result.device)
-        out = {"Test PSNR": psnr(result, gt)}
-        if result.is_cuda:
-            out["Test SSIM"], out["Test FSIM"], out["Test iCID"] = ssim(result, gt), fsim(result, gt), icid(result, gt)
+        out = {}
+        fns = {"psnr": ("Test PSNR", psnr), "ssim": ("Test SSIM", ssim), "fsim": ("Test FSIM", fsim), "icid": ("Test iCID", icid)}
+        for m in self.metrics:
+            if m == "psnr" or result.is_cuda:        # SSIM / FSIM / iCID exist on the GPU only
+                out[fns[m][0]] = fns[m][1](result, gt)
         return out

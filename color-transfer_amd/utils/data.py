@@ -201,10 +201,89 @@ def prefetch(dataset, indices, device):
         yield index, (dev if extra == "float" else dataset.finish(dev, extra))
 
 
+class SyntheticStereoVideoU8:
+    """BASELINE.json configs[4]: a synthetic 1080p stereo video of uint8 frames -- what every real frame is (the reference's
+    datasets decode to uint8 and divide by 255, utils/data.py:84,106,125) -- handed over as PINNED HOST chunks of `group`
+    consecutive frames per rank, [3 roles: target, reference, gt][group][H][W][3].  Decoding / generating 1000 distinct frames on
+    the host would measure the host, so the frames cycle through a pool of `pool` distinct chunks (seeded 4321 + i)."""
+    roles = ("target", "reference", "gt")
+
+    def __init__(self, n_frames=1000, height=1080, width=1920, group=4, pool=8):
+        self.n_frames, self.height, self.width, self.group, self.pool = int(n_frames), int(height), int(width), int(group), int(pool)
+        self._chunks = None
+
+    def __len__(self):
+        return self.n_frames
+
+    def _pool(self):
+        if self._chunks is None:
+            self._chunks = []
+            for i in range(self.pool):
+                rng = np.random.default_rng(4321 + i)
+                trip = rng.integers(0, 256, (3, self.group, self.height, self.width, 3), dtype=np.uint8)
+                t = torch.from_numpy(trip)
+                self._chunks.append(t.pin_memory() if torch.cuda.is_available() else t)
+        return self._chunks
+
+    def host_chunk(self, first_frame):
+        """the pinned chunk whose first frame is `first_frame` (frame f of the video = frame f of chunk pool[f % pool])"""
+        return self._pool()[first_frame % self.pool]
+
+    def __getitem__(self, f):
+        """one frame as the reference's sample dict (float32 CHW in [0,1]): the per-sample path of utils.cli"""
+        c = self._pool()[f % self.pool][:, 0]
+        return {k: (c[i].permute(2, 0, 1).float() / 255) for i, k in enumerate(self.roles)}
+
+
+def prefetch_groups(dataset, indices, device, depth=3):
+    """Yield (frame indices of the group, device uint8 tensor [3, k, H, W, 3]) for a dataset with `host_chunk` (pinned uint8 chunks
+    of `dataset.group` frames): the uploads run on a copy stream, depth - 1 uploads ahead of the consumer, through a ring of
+    `depth` device buffers; a buffer is overwritten only after the kernels that read its previous chunk are done (the consumer's
+    stream is the current one when the generator is advanced).  One 75 MB copy per group of four 1080p triples: single-triple
+    copies reach 47.8 GB/s on this host, these 51-53."""
+    indices = list(indices)
+    g = dataset.group
+    n_chunks = (len(indices) + g - 1) // g
+    if n_chunks == 0:
+        return
+    copy_stream = torch.cuda.Stream(device=device)
+    main = torch.cuda.current_stream(device)
+    first = dataset.host_chunk(indices[0])
+    ring = [torch.empty(first.shape, dtype=first.dtype, device=device) for _ in range(depth)]
+    uploaded = [torch.cuda.Event() for _ in range(depth)]
+    consumed = [torch.cuda.Event() for _ in range(depth)]
+
+    def count(c):
+        return min(g, len(indices) - c * g)
+
+    def upload(c):
+        slot, k = c % depth, count(c)
+        with torch.cuda.stream(copy_stream):
+            if c >= depth:
+                copy_stream.wait_event(consumed[slot])
+            src = dataset.host_chunk(indices[c * g])
+            if k == g:
+                ring[slot].copy_(src, non_blocking=True)
+            else:                                               # ragged last chunk: only the frames that exist
+                ring[slot][:, :k].copy_(src[:, :k], non_blocking=True)
+            uploaded[slot].record(copy_stream)
+
+    for c in range(min(depth - 1, n_chunks)):
+        upload(c)
+    for c in range(n_chunks):
+        if c + depth - 1 < n_chunks:
+            upload(c + depth - 1)
+        slot, k = c % depth, count(c)
+        main.wait_event(uploaded[slot])
+        yield indices[c * g:c * g + k], ring[slot][:, :k]
+        consumed[slot].record(main)
+
+
 class DataModule:
     """Accepts the reference's init_args (data_dir, num_workers, crop_size, ...).  `test_frames()` = the reference's first test
     loader (ArtificialTestDataset over data_dir / "Test") when that directory exists; otherwise a synthetic stand-in:
-    `synthetic: video` (default, n_frames float frames) or `synthetic: artificial` (n_frames uint8 pairs x 31 distortions)."""
+    `synthetic: video` (default, n_frames float frames), `synthetic: artificial` (n_frames uint8 pairs x 31 distortions) or
+    `synthetic: video_u8` (n_frames uint8 frames in pinned groups of four: configs[4])."""
 
     def __init__(self, data_dir=None, num_workers=0, crop_size=None, image_repeats=None, batch_size=None,
                  n_frames=8, height=270, width=480, synthetic="video", **_):
@@ -213,6 +292,8 @@ class DataModule:
             self.dataset = ArtificialTestDataset(self.data_dir / "Test")
         elif synthetic == "artificial":
             self.dataset = SyntheticArtificialTest(n_frames, height, width)
+        elif synthetic == "video_u8":
+            self.dataset = SyntheticStereoVideoU8(n_frames, height, width)
         else:
             self.dataset = SyntheticStereoFrames(n_frames, height, width)
 

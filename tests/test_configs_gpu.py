@@ -160,3 +160,36 @@ def test_config5_sharded_video_world1(capsys):
         mse = ((ref.astype(np.float64) - gt.astype(np.float64)) ** 2).mean()
         want = 10 * np.log10(1 / mse)
         assert abs(float(table[f, 0]) - want) <= 1e-4, (f, float(table[f, 0]), want)
+
+
+def test_config5_u8_video_grouped_through_the_cli(capsys):
+    """configs[4] as bench.py measures it: uint8 1080p frames in pinned groups of four through utils.cli -> Runner.test_group ->
+    ct_reinhard_psnr_u8 (one upload and one fused call per group, metrics = psnr).  Every frame's PSNR equals the direct call
+    on the same bytes bit for bit; two frames are re-computed with the CPU oracle; the ragged last group (n % 4 != 0) and the
+    timing hook bench.py uses are covered."""
+    import ct_hip
+    from utils import cli
+    from utils.data import SyntheticStereoVideoU8
+    n = 22
+    timing = {}
+    table = cli.main(["test", "--config", os.path.join(ROOT, "color-transfer_amd", "configs", "others.yaml"), "--model.metrics", "psnr",
+                      "--data.data_dir", "null", "--data.synthetic", "video_u8", "--data.n_frames", str(n), "--data.height", "1080",
+                      "--data.width", "1920"], timing=timing)
+    out = capsys.readouterr().out
+    assert "Test PSNR" in out and "Test SSIM" not in out
+    assert table.shape == (n, 4) and torch.isfinite(table[:, 0]).all() and torch.isnan(table[:, 1:]).all()
+    assert timing["grouped"] is True and timing["frames"] == n and timing["frames_local"] == n and timing["frames_per_call"] == 4
+    assert timing["seconds"] > 0 and timing["h2d_bytes"] == n * 3 * 1080 * 1920 * 3
+    video = SyntheticStereoVideoU8(n, 1080, 1920)
+    for first in (0, 4, 20):                                             # group starting at frame `first` = pool chunk first % 8
+        chunk = video.host_chunk(first).cuda()
+        k = min(4, n - first)
+        _, ps = ct_hip.reinhard_persist(chunk[0, :k], chunk[1, :k], gt=chunk[2, :k], verify=True)
+        assert torch.equal(table[first:first + k, 0], ps[:, 1])
+    for f in (1, 21):
+        c = video.host_chunk(f - f % 4)
+        t, r, gt = ((c[i, f % 4].numpy().astype(np.float32) / np.float32(255)) for i in range(3))
+        ref = np.clip(olin.color_transfer_between_images(t, r), 0, 1)
+        mse = ((ref.astype(np.float64) - gt.astype(np.float64)) ** 2).mean()
+        assert abs(float(table[f, 0]) - 10 * np.log10(1 / mse)) <= 1e-4
+    assert ct_hip.device_status() == 0
