@@ -80,8 +80,8 @@ def video_stream(n_frames, rank, world):
     """BASELINE.json configs[4] through the PRODUCT'S entry point: `utils.cli test --config configs/others.yaml --model.metrics psnr
     --data.synthetic video_u8 --data.n_frames N` (the reference's way in, utils/cli.py:1-3; methods/__init__.py:18-40).  This
     rank's share of an n_frames 1080p stereo video (frame f -> rank f % world) arrives as uint8 frames in pinned host memory (the
-    host-buffer hand-over of the drop-in boundary: PCIe is inside this measurement, unlike `value`), four stereo triples per
-    upload on a copy stream two uploads ahead; Runner.test_group corrects and scores four pairs per call
+    host-buffer hand-over of the drop-in boundary: PCIe is inside this measurement, unlike `value`), eight stereo triples per
+    upload (149 MB) on a copy stream two uploads ahead; Runner.test_group corrects and scores eight pairs per call
     (ct_reinhard_psnr_u8 reads the bytes; clamp + PSNR of Runner.test_step fused); ONE gather of the [frames, metrics] table
     at the end.  Timed by utils.cli.main itself (barrier + synchronize on both sides, max over ranks)."""
     from utils import cli
@@ -433,6 +433,16 @@ def main():
             gr = 1e3 / tgm["median_ms"]
             extra["gmflow_960x540_pairs_per_s_f32"] = gr
             extra["gmflow_960x540_forward"] = tgm
+            # the metric is pairs/s: the module takes B pairs per forward (unimatch/__init__.py:60-67 does too), and at batch 1 most
+            # launches of this network are 448 one-unit workgroups on 256 CUs (one 87 %-filled round); larger batches fill their rounds
+            by_batch = {1: gr}
+            for nb in (2, 4):
+                an, bn = torch.rand(nb, 3, 540, 960, device=device) * 255, torch.rand(nb, 3, 540, 960, device=device) * 255
+                tb = forward_ms(lambda: gm(an, bn, inference_size=size, pred_bidir_flow=True, fwd_bwd_consistency_check=True), n=6, warm=2)
+                by_batch[nb] = nb * 1e3 / tb["median_ms"]
+                del an, bn
+            extra["gmflow_960x540_pairs_per_s_f32_by_batch"] = by_batch
+            extra["gmflow_960x540_pairs_per_s_f32_best_batch"] = max(by_batch.values())
             # the reference's algorithmic FLOPs per pair; 0.376e12 of them (the SepConvGRU's loop-invariant input blocks)
             # are convolved once per forward instead of once per refinement iteration, so this is a throughput equivalent
             extra["gmflow_960x540_tflops_f32_equivalent"] = 3.58357106688e12 * gr / 1e12

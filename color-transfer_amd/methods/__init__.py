@@ -76,7 +76,7 @@ class Runner(torch.nn.Module):
         import ct_hip
         k = group_u8.shape[1]
         if self._out is None or self._out.shape[1:] != group_u8.shape[2:] or self._out.shape[0] < k or self._out.device != group_u8.device:
-            self._out = torch.empty((max(k, 4),) + tuple(group_u8.shape[2:]), dtype=torch.float32, device=group_u8.device)
+            self._out = torch.empty((k,) + tuple(group_u8.shape[2:]), dtype=torch.float32, device=group_u8.device)
         ct_hip.reinhard_persist(group_u8[0], group_u8[1], gt=group_u8[2], out=self._out[:k], psnr_out=psnr_out)
         return self._out[:k]
 

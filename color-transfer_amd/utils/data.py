@@ -204,11 +204,11 @@ def prefetch(dataset, indices, device):
 class SyntheticStereoVideoU8:
     """BASELINE.json configs[4]: a synthetic 1080p stereo video of uint8 frames -- what every real frame is (the reference's
     datasets decode to uint8 and divide by 255, utils/data.py:84,106,125) -- handed over as PINNED HOST chunks of `group`
-    consecutive frames per rank, [3 roles: target, reference, gt][group][H][W][3].  Decoding / generating 1000 distinct frames on
+    consecutive frames per rank (default 8), [3 roles: target, reference, gt][group][H][W][3].  Decoding / generating 1000 distinct frames on
     the host would measure the host, so the frames cycle through a pool of `pool` distinct chunks (seeded 4321 + i)."""
     roles = ("target", "reference", "gt")
 
-    def __init__(self, n_frames=1000, height=1080, width=1920, group=4, pool=8):
+    def __init__(self, n_frames=1000, height=1080, width=1920, group=8, pool=8):
         self.n_frames, self.height, self.width, self.group, self.pool = int(n_frames), int(height), int(width), int(group), int(pool)
         self._chunks = None
 
@@ -239,8 +239,8 @@ def prefetch_groups(dataset, indices, device, depth=3):
     """Yield (frame indices of the group, device uint8 tensor [3, k, H, W, 3]) for a dataset with `host_chunk` (pinned uint8 chunks
     of `dataset.group` frames): the uploads run on a copy stream, depth - 1 uploads ahead of the consumer, through a ring of
     `depth` device buffers; a buffer is overwritten only after the kernels that read its previous chunk are done (the consumer's
-    stream is the current one when the generator is advanced).  One 75 MB copy per group of four 1080p triples: single-triple
-    copies reach 47.8 GB/s on this host, these 51-53."""
+    stream is the current one when the generator is advanced).  Copy size is what the PCIe rate hangs on (measured round 5,
+    1080p triples, same box): one triple per copy 47.8 GB/s, four (75 MB) 49-52, eight (149 MB, the default group) 56."""
     indices = list(indices)
     g = dataset.group
     n_chunks = (len(indices) + g - 1) // g
@@ -283,17 +283,17 @@ class DataModule:
     """Accepts the reference's init_args (data_dir, num_workers, crop_size, ...).  `test_frames()` = the reference's first test
     loader (ArtificialTestDataset over data_dir / "Test") when that directory exists; otherwise a synthetic stand-in:
     `synthetic: video` (default, n_frames float frames), `synthetic: artificial` (n_frames uint8 pairs x 31 distortions) or
-    `synthetic: video_u8` (n_frames uint8 frames in pinned groups of four: configs[4])."""
+    `synthetic: video_u8` (n_frames uint8 frames in pinned groups of `group` = 8: configs[4])."""
 
     def __init__(self, data_dir=None, num_workers=0, crop_size=None, image_repeats=None, batch_size=None,
-                 n_frames=8, height=270, width=480, synthetic="video", **_):
+                 n_frames=8, height=270, width=480, synthetic="video", group=8, **_):
         self.data_dir = Path(data_dir) if data_dir else None
         if self.data_dir is not None and (self.data_dir / "Test").is_dir():
             self.dataset = ArtificialTestDataset(self.data_dir / "Test")
         elif synthetic == "artificial":
             self.dataset = SyntheticArtificialTest(n_frames, height, width)
         elif synthetic == "video_u8":
-            self.dataset = SyntheticStereoVideoU8(n_frames, height, width)
+            self.dataset = SyntheticStereoVideoU8(n_frames, height, width, group=group)
         else:
             self.dataset = SyntheticStereoFrames(n_frames, height, width)
 
