@@ -265,13 +265,13 @@ def main():
         # HBM traffic per launch of the dominant kernel from the committed PMC profile (separate --pmc passes,
         # FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md "HBM"), valid for the same pairs-per-step only
         traffic = None
-        tj = read_stamped(os.path.join(ROOT, "profiles", "r04_traffic.json"))     # None unless measured on THIS tree's kernel sources
+        tj = read_stamped(os.path.join(ROOT, "profiles", "r05_traffic.json"))     # None unless measured on THIS tree's kernel sources
         if tj and tj.get("pairs_per_step") == B and tj.get("lab_mode") == ct_hip.lab_mode():
             traffic = tj.get("hbm_bytes_per_launch", {}).get(dom)
         t_kernels = t_stats + t_apply
         roof = {"bound": "hbm", "kernel": dom, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": ach / HBM_PEAK, "traffic": traffic,
-                "traffic_source": ("profiles/r04_traffic.json (rocprofv3 --pmc passes of this command on a build with source stamp %s; not live)" % source_stamp()) if traffic
+                "traffic_source": ("profiles/r05_traffic.json (rocprofv3 --pmc passes of this command on a build with source stamp %s; not live)" % source_stamp()) if traffic
                 else "no PMC profile of this build under profiles/ (stamp %s)" % source_stamp(),
                 "algorithmic_bytes_per_launch": kern[dom]["bytes"],
                 "algorithmic_bytes_note": "2 float32 planes x %d pairs (SURVEY 8d): %s" % (
@@ -403,7 +403,7 @@ def main():
             # kernels run on: 6 bf16 MFMAs per float32 product in the convolutions and the q.k scores); `frac` = MFMA-busy from
             # the committed counter profile of the same forward (SQ_VALU_MFMA_BUSY_CYCLES over all kernels of the run, time
             # weighted, profiles/r02_dcmcs3di_1080p_mfma_pmc.json); achieved = issued bf16-MFMA-equivalent work, live.
-            busy = read_stamped(os.path.join(ROOT, "profiles", "r04_dcmcs3di_1080p_mfma_pmc.json")) or {}      # {} unless measured on this tree's sources
+            busy = read_stamped(os.path.join(ROOT, "profiles", "r05_dcmcs3di_1080p_mfma_pmc.json")) or {}      # {} unless measured on this tree's sources
             kdom = [v for k, v in busy.items() if "conv_ws_kernel" in k]
             roof_cnn = {"bound": "mfma", "workload": "dcmcs3di forward, random init, 1 pair of 1920x1080, float32 I/O",
                         "dtype": "16-bit MFMA pipe (float32 operands as 2 fp16 pieces / 3 MFMAs per product in the convolutions and the "
@@ -411,7 +411,7 @@ def main():
                         "achieved": mfma_per_flop * flop2 * dc2 / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                         "frac_flops": mfma_per_flop * flop2 * dc2 / 2.5e15,
                         "frac": busy.get("_all_kernels", {}).get("mfma_busy_frac_time_weighted"),
-                        "frac_source": ("profiles/r04_dcmcs3di_1080p_mfma_pmc.json: ONE rocprofv3 --pmc run of the same forward on a build with source "
+                        "frac_source": ("profiles/r05_dcmcs3di_1080p_mfma_pmc.json: ONE rocprofv3 --pmc run of the same forward on a build with source "
                                         "stamp %s (not live)" % source_stamp()) if busy else
                                        "no PMC profile of this build under profiles/ (source stamp %s): frac is null, never a stale number" % source_stamp(),
                         "forward": t1080,
@@ -458,7 +458,7 @@ def main():
                 "noise_flow_40px_per_pixel_form": forward_ms(lambda: ct_hip.local_corr_flow(tk, tk, noise, 4))["median_ms"] * 1e3,
                 "note": "128x224 tokens, batch 2, radius 4; the forward above (random weights) runs the second case 6 times per pair"}
             del tk, smooth, noise
-            gmp = read_stamped(os.path.join(ROOT, "profiles", "r04_gmflow_960x540_mfma_pmc.json"))
+            gmp = read_stamped(os.path.join(ROOT, "profiles", "r05_gmflow_960x540_mfma_pmc.json"))
             extra["gmflow_960x540_mfma_busy_time_weighted"] = gmp.get("_all_kernels", {}).get("mfma_busy_frac_time_weighted") if gmp else None
             if gmp:
                 extra["gmflow_960x540_mfma_busy_note"] = ("MFMA-busy is not comparable across arithmetic forms: the fp16 two-piece kernels issue "

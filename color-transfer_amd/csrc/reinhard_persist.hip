@@ -211,12 +211,13 @@ __device__ __forceinline__ bool fwd_tile(const unsigned char *tab, Scratch *sc, 
         float fy, dxy, dyz;
         if constexpr (!PARK) {
             // the reference frame only feeds the statistics: plain float32 values of f(), unbiased per pixel
-            // (cube roots from the transcendental unit: this kernel is short of LDS cycles, ct_color_lut.h)
+            // (cube roots from table F here, unlike the two-sweep statistics kernel: this launch is bound by vector issue -- 340
+            // instructions per pixel pair at ~4 cycles each -- and the transcendental form costs three more per cube root)
             if constexpr (sizeof(T) == 4) {
-                lut::rgb_to_f_stats_hw(tab, cur.e[3 * q], cur.e[3 * q + 1], cur.e[3 * q + 2], fy, dxy, dyz);
+                lut::rgb_to_f_stats(tab, cur.e[3 * q], cur.e[3 * q + 1], cur.e[3 * q + 2], fy, dxy, dyz);
             } else {
                 const float l[3] = {sc->lin255f[byte_of(cur.d, 3 * q)], sc->lin255f[byte_of(cur.d, 3 * q + 1)], sc->lin255f[byte_of(cur.d, 3 * q + 2)]};
-                lut::lin_to_f_stats_hw(l, fy, dxy, dyz);
+                lut::lin_to_f_stats(tab, l, fy, dxy, dyz);
             }
         } else {
             if constexpr (sizeof(T) == 4) {

@@ -55,15 +55,27 @@ def test_stamp_gates_profile_reads(tmp_path):
     assert stamp.read_stamped(str(tmp_path / "missing.json")) is None
 
 
-def test_committed_r04_profiles_carry_a_stamp():
-    """every round-4 JSON summary under profiles/ says which sources it was measured on (it may be older than HEAD: then bench.py
-    prints null for the numbers it would have quoted, which is the point)"""
+def test_committed_profiles_carry_a_stamp():
+    """every JSON summary of rounds 4 and 5 under profiles/ says which sources it was measured on (it may be older than HEAD: then
+    bench.py prints null for the numbers it would have quoted, which is the point)"""
     import glob
-    js = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r04_*.json")) if "bench" not in os.path.basename(f)]
-    assert js, "no round-4 profile summaries committed"
+    js = [f for r in ("r04", "r05") for f in glob.glob(os.path.join(ROOT, "profiles", r + "_*.json")) if "bench" not in os.path.basename(f)]
+    assert js, "no profile summaries committed"
     for f in js:
         j = json.load(open(f))
         assert isinstance(j.get("source_stamp"), str) and len(j["source_stamp"]) == 16, f
-    for f in glob.glob(os.path.join(ROOT, "profiles", "r04_*mfma_pmc.json")):
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r0[45]_*mfma_pmc.json")):
         j = json.load(open(f))
         assert j["_ignored_runs"] == [] and j["_run"].endswith("counter_collection.csv"), f
+
+
+def test_no_build_artefacts_are_tracked():
+    """ISA dumps and object files under csrc/build_* (make asm / tuning builds) never enter the history (+437 k lines
+    twice); neither do shared objects or anything under gpurun_out/"""
+    import subprocess
+    if not os.path.isdir(os.path.join(ROOT, ".git")):
+        import pytest
+        pytest.skip("not a git checkout (the GPU box runs a snapshot)")
+    files = subprocess.run(["git", "-C", ROOT, "ls-files"], capture_output=True, text=True, check=True).stdout.splitlines()
+    bad = [f for f in files if "/csrc/build" in f or f.startswith("gpurun_out/") or f.endswith((".so", ".o", ".s", ".hsaco", ".bc", ".hipi"))]
+    assert not bad, bad[:10]

@@ -1,19 +1,20 @@
 #!/usr/bin/env python3
-"""gpurun_out/prof_r04 (written on the GPU box by tools/gpu_profile_r04.sh) -> the tracked summaries under profiles/, each
+"""gpurun_out/prof_<round> (written on the GPU box by tools/gpu_profile_round.sh) -> the tracked summaries under profiles/, each
 stamped with the source stamp of the build that was measured (tools/stamp.py; refused when it is not this tree's):
-kernel-stats CSVs, bench JSON lines, HBM traffic + instruction counts of the Reinhard kernels (r04_traffic.json), MFMA-busy
+kernel-stats CSVs, bench JSON lines, HBM traffic + instruction counts of the Reinhard kernels (<round>_traffic.json), MFMA-busy
 summaries of the CNN forwards."""
 import csv, glob, json, os, shutil, subprocess, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "prof_r04")
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r05"
+SRC = os.path.join(ROOT, "gpurun_out", "prof_" + ROUND)
 DST = os.path.join(ROOT, "profiles")
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from stamp import source_stamp
 STAMP = open(os.path.join(SRC, "source_stamp.txt")).read().strip()
 if STAMP != source_stamp():
-    sys.exit("gpurun_out/prof_r04 was measured on sources with stamp %s, this tree has %s: re-run tools/gpu_profile_r04.sh" % (STAMP, source_stamp()))
+    sys.exit("gpurun_out/prof_<round> was measured on sources with stamp %s, this tree has %s: re-run tools/gpu_profile_round.sh" % (STAMP, source_stamp()))
 try:
     HEAD = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
     DIRTY = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "color-transfer_amd/csrc", "include"], capture_output=True, text=True).stdout.strip())
@@ -45,13 +46,13 @@ def counters(sub):
     return {k: {c: v[0] / v[1] for c, v in d.items()} for k, d in agg.items()}
 
 
-stats_csv("trace", "r04_reinhard_bench_kernel_stats.csv")
-stats_csv("trace_dc1080", "r04_dcmcs3di_1080p_kernel_stats.csv")
-stats_csv("trace_gm960", "r04_gmflow_960x540_kernel_stats.csv")
-stats_csv("trace_dmsct960", "r04_dmsct_960x540_kernel_stats.csv")
-stats_csv("trace_idt", "r04_idt_kernel_stats.csv")
-for a, b in (("bench_under_rocprofv3.json", "r04_bench_under_rocprofv3.json"), ("bench_default.json", "r04_bench_default.json"),
-             ("bench_20_5.json", "r04_bench_20_5.json")):
+stats_csv("trace", ROUND + "_reinhard_bench_kernel_stats.csv")
+stats_csv("trace_dc1080", ROUND + "_dcmcs3di_1080p_kernel_stats.csv")
+stats_csv("trace_gm960", ROUND + "_gmflow_960x540_kernel_stats.csv")
+stats_csv("trace_dmsct960", ROUND + "_dmsct_960x540_kernel_stats.csv")
+stats_csv("trace_idt", ROUND + "_idt_kernel_stats.csv")
+for a, b in (("bench_under_rocprofv3.json", ROUND + "_bench_under_rocprofv3.json"), ("bench_default.json", ROUND + "_bench_default.json"),
+             ("bench_20_5.json", ROUND + "_bench_20_5.json")):
     p = os.path.join(SRC, a)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(DST, b)); print("wrote", b)
@@ -69,7 +70,7 @@ for sub in sorted(os.listdir(SRC)):
                 per[short].update(d)
 alg = 2 * 3 * 4 * H * W * pairs            # two float32 frames per pair, read or written once by each sweep
 out = {**STAMPS, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* in separate passes over `bench.py --steps 20 --warmup 5` "
-                 "(tools/gpu_profile_r04.sh, tools/collect_profiles_r04.py)",
+                 "(tools/gpu_profile_round.sh, tools/collect_profiles_round.py)",
        "pairs_per_step": pairs, "lab_mode": bench["config"].get("lab_arithmetic"),
        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE x 1024 (MI355X_MICROARCH.md, HBM)",
        "hbm_bytes_per_launch": {}, "algorithmic_bytes_per_launch": alg, "per_kernel": {}}
@@ -87,8 +88,8 @@ for k, d in per.items():
         e["valu_instructions_per_pixel"] = d["SQ_INSTS_VALU"] * 64 / px
         e["all_counted_instructions_per_pixel"] = sum(d.get(c, 0.0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")) * 64 / px
     out["per_kernel"][k] = e
-json.dump(out, open(os.path.join(DST, "r04_traffic.json"), "w"), indent=1)
-print("wrote r04_traffic.json", out["hbm_bytes_per_launch"])
+json.dump(out, open(os.path.join(DST, ROUND + "_traffic.json"), "w"), indent=1)
+print("wrote", ROUND + "_traffic.json", out["hbm_bytes_per_launch"])
 
 # ---- IDT: HBM bytes per launch of its kernels (same gfx950 correction)
 idt = defaultdict(dict)
@@ -105,11 +106,11 @@ if idt:
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
             e["read_bytes_mean_per_launch"], e["write_bytes_mean_per_launch"] = int(2 * d["FETCH_SIZE"] * 1024), int(d["WRITE_SIZE"] * 1024)
         o["per_kernel"][k] = e
-    json.dump(o, open(os.path.join(DST, "r04_idt_traffic.json"), "w"), indent=1)
-    print("wrote r04_idt_traffic.json")
+    json.dump(o, open(os.path.join(DST, ROUND + "_idt_traffic.json"), "w"), indent=1)
+    print("wrote", ROUND + "_idt_traffic.json")
 
 # ---- MFMA-busy of the CNN forwards: summarised on the GPU box from ONE run each (tools/summarize_pmc.py there)
-for a, b in (("dcmcs3di_1080p_mfma_pmc.json", "r04_dcmcs3di_1080p_mfma_pmc.json"), ("gmflow_960x540_mfma_pmc.json", "r04_gmflow_960x540_mfma_pmc.json")):
+for a, b in (("dcmcs3di_1080p_mfma_pmc.json", ROUND + "_dcmcs3di_1080p_mfma_pmc.json"), ("gmflow_960x540_mfma_pmc.json", ROUND + "_gmflow_960x540_mfma_pmc.json")):
     p = os.path.join(SRC, a)
     if os.path.exists(p) and os.path.getsize(p):
         j = json.load(open(p))
@@ -119,7 +120,7 @@ for a, b in (("dcmcs3di_1080p_mfma_pmc.json", "r04_dcmcs3di_1080p_mfma_pmc.json"
         print("wrote", b, j["_all_kernels"])
 
 # ---- the persistent launch: kernel stats + HBM bytes per launch (float32 and uint8 instantiations)
-stats_csv("trace_persist", "r04_reinhard_persist_kernel_stats.csv")
+stats_csv("trace_persist", ROUND + "_reinhard_persist_kernel_stats.csv")
 pp = defaultdict(dict)
 for sub in ("persist_FETCH_SIZE", "persist_WRITE_SIZE"):
     if os.path.isdir(os.path.join(SRC, sub)):
@@ -137,5 +138,5 @@ if pp:
             e["algorithmic_bytes_per_launch"] = 16 * H * W * 3 * (3 * in_b + 4)        # target, reference, ground truth in; float32 result out
             e["traffic_over_algorithmic"] = (e["read_bytes_per_launch"] + e["write_bytes_per_launch"]) / e["algorithmic_bytes_per_launch"]
         o["per_kernel"][k] = e
-    json.dump(o, open(os.path.join(DST, "r04_reinhard_persist_traffic.json"), "w"), indent=1)
-    print("wrote r04_reinhard_persist_traffic.json")
+    json.dump(o, open(os.path.join(DST, ROUND + "_reinhard_persist_traffic.json"), "w"), indent=1)
+    print("wrote", ROUND + "_reinhard_persist_traffic.json")

@@ -1,10 +1,11 @@
 #!/bin/bash
-# GPU box (through gpurun): round-4 profiles.  Kernel-trace stats of the default bench command, separate PMC passes for HBM
+# GPU box (through gpurun): profiles of one round (ROUND=r05 by default).  Kernel-trace stats of the default bench command, separate PMC passes for HBM
 # traffic / instruction counts of the Reinhard kernels, ONE MFMA-busy run per CNN forward (summarised here, on the box, where only
 # this call's files exist), IDT stats + traffic.  Everything carries the source stamp of the build it ran (tools/stamp.py).
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/prof_r04
+ROUND=${ROUND:-r05}
+OUT=$ROOT/gpurun_out/prof_$ROUND
 rm -rf $OUT; mkdir -p $OUT
 python3 $ROOT/tools/stamp.py > $OUT/source_stamp.txt
 cd /tmp && export TMPDIR=/tmp
