@@ -74,7 +74,7 @@ struct Scratch {
     float lut255[256];                // uint8 frames: (float)k / 255
     float lin255f[256];               // uint8 frames: gamma expansion of lut255[k] (table E)
     unsigned cnt[2];
-    unsigned ticket[2];               // arrivals of the waves at A(p), by pair parity: the first one collects the statistics
+    unsigned ticket[3];               // arrivals of the waves at A(p), by pair % 3: the first one collects the statistics
     unsigned ready[2];                // p + 1 once the coefficients of pair p are in coef[p & 1]
     int flag[2];                      // bit 0: some partial sum did not fit the integer format, bit 1: timed out
 };
@@ -458,7 +458,8 @@ __global__ __launch_bounds__(kWaves * kWave) void reinhard_persist_kernel(const 
         if constexpr (sizeof(T) == 4) { p0[0] = p[0]; p0[1] = p[1]; p0[2] = p[2]; }
         else { p0[0] = (float)p[0] / 255.0f; p0[1] = (float)p[1] / 255.0f; p0[2] = (float)p[2] / 255.0f; }
     }
-    if (threadIdx.x < 2) { sc->cnt[threadIdx.x] = 0; sc->flag[threadIdx.x] = 0; sc->ticket[threadIdx.x] = 0; sc->ready[threadIdx.x] = 0; }
+    if (threadIdx.x < 2) { sc->cnt[threadIdx.x] = 0; sc->flag[threadIdx.x] = 0; sc->ready[threadIdx.x] = 0; }
+    if (threadIdx.x < 3) sc->ticket[threadIdx.x] = 0;
     if (sizeof(T) == 1 && threadIdx.x < 256) sc->lut255[threadIdx.x] = (float)threadIdx.x / 255.0f;     // IEEE division: the reference's .float() / 255
     __syncthreads();
     if (sizeof(T) == 1 && threadIdx.x < 256) {                   // exactly what the float32 kernel computes for the value k / 255
@@ -582,7 +583,13 @@ __global__ __launch_bounds__(kWaves * kWave) void reinhard_persist_kernel(const 
         bool timed_out = false;
         {
             unsigned tk = 0;
-            if (lane == 0) tk = atomicAdd(&sc->ticket[par], 1u);
+            // pair % 3, not parity: a wave ARRIVES at A(p + 2) as soon as it has passed A(p + 1), i.e. once every wave of the grid has
+            // published pair p + 1 -- which every wave does before it arrives at A(p).  The fastest wave can so be two apply phases
+            // ahead of the slowest one's ARRIVAL (never of its passing: that needs pair p + 2 published, after A(p) in program order),
+            // and a ticket shared by A(p) and A(p + 2) could be handed out twice.  (Found in round 5 with an experimental schedule whose
+            // last apply phases follow each other without a sweep in between; this schedule has a sweep there, which made the race
+            // a matter of tens of microseconds of skew rather than impossible.)
+            if (lane == 0) tk = atomicAdd(&sc->ticket[p % 3], 1u);
             tk = __builtin_amdgcn_readfirstlane(tk);
             if (tk == 0) {
                 const int rc0 = collect(a.rec + (size_t)p * kShards * kRecWords, nwg, lane, sc, a.err);
@@ -594,7 +601,7 @@ __global__ __launch_bounds__(kWaves * kWave) void reinhard_persist_kernel(const 
                 }
                 CT_RP_STAMP(1);
             }
-            if (tk == kWaves - 1 && lane == 0) sc->ticket[par] = 0;                  // every wave is here: free for A(p + 2)
+            if (tk == kWaves - 1 && lane == 0) sc->ticket[p % 3] = 0;                // every wave is here: free for A(p + 3)
             // bounded like every other spin of this kernel (the collecting wave gives up after kSpinTicks itself and then publishes
             // rc = 2: this bound is a second line of defence, 2 x kSpinTicks)
             bool ready_ok = true;
