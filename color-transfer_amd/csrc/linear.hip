@@ -50,7 +50,7 @@ static WsLayout ws_carve(void *ws, int n_images) {
 
 // grid = (G, n_images). Images [0, n_first) live at base0, the rest at base1 (so that the
 // targets and references of a batch of pairs are swept by ONE launch).
-// CT_WPE: optional occupancy attribute for tuning builds (tools/sweep_reinhard.sh); forcing 8 waves/SIMD spills and
+// CT_WPE: optional occupancy attribute for tuning builds (tools/build_variant.sh); forcing 8 waves/SIMD spills and
 // is slower, the kernels are VALU-bound and insensitive to the grid (measured r01).
 #ifndef CT_WPE
 #define CT_WPE
