@@ -79,7 +79,7 @@ class IdtDebug(ctypes.Structure):
     _fields_ = [("hist", _c_p), ("lut", _c_p), ("par", _c_p), ("binidx", _c_p)]
 
 _lib = None
-_lock = threading.Lock()
+_lock = threading.RLock()          # re-entrant: lib() takes it on first use, possibly under a caller that already holds it
 
 
 class CtHipError(RuntimeError):
@@ -741,12 +741,13 @@ def _conv_scratch(device):
     node of that graph only), so a later graph on the same capture stream would share memory the allocator may already have
     handed out again -- such launches run without stream-K instead (every workgroup computes whole units, same results)."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    need = lib().ct_conv_split_scratch_bytes()      # outside the lock: lib() takes it on first use
     with _lock:
         buf = _sk_cache.get(key)
         if buf is None:
             if torch.cuda.is_current_stream_capturing():
                 return None
-            buf = torch.zeros(lib().ct_conv_split_scratch_bytes(), dtype=torch.uint8, device=device)
+            buf = torch.zeros(need, dtype=torch.uint8, device=device)
             _sk_cache[key] = buf
     return buf
 

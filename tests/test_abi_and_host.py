@@ -244,3 +244,18 @@ def test_conv_scratch_argument_checks_without_a_gpu():
     assert call(aligned, need) == 0                                     # ... with a well-formed scratch too
     assert call(aligned, need - 1) == -2                                # CT_E_WORKSPACE: too small
     assert call(ctypes.c_void_p(aligned.value + 4), need) == -2         # misaligned
+
+
+def test_first_library_use_through_any_entry_cannot_deadlock():
+    """Round 5 regression: the stream-K scratch helper took the binding's lock and then called lib(), which takes it on first
+    use -- a process whose FIRST library call was a tile convolution hung forever (tools/bench_dcmcs3di.py under rocprofv3; bench.py
+    and the tests load the library earlier and never saw it).  Fresh interpreter, no GPU: the call must come back (with the error of
+    the missing device), not hang."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path[:0] = [%r, %r]\\n"
+            "import torch, ct_hip\\n"
+            "try:\\n    ct_hip._conv_scratch(torch.device('cuda', 0))\\nexcept Exception as e:\\n    print('raised', type(e).__name__)\\n"
+            "print('lib loaded', ct_hip._lib is not None)\\n") % (ROOT, os.path.join(ROOT, "color-transfer_amd"))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert "lib loaded True" in p.stdout, (p.stdout, p.stderr[-500:])
