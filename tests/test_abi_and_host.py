@@ -253,9 +253,9 @@ def test_first_library_use_through_any_entry_cannot_deadlock():
     the missing device), not hang."""
     import subprocess
     import sys
-    code = ("import sys; sys.path[:0] = [%r, %r]\\n"
-            "import torch, ct_hip\\n"
-            "try:\\n    ct_hip._conv_scratch(torch.device('cuda', 0))\\nexcept Exception as e:\\n    print('raised', type(e).__name__)\\n"
-            "print('lib loaded', ct_hip._lib is not None)\\n") % (ROOT, os.path.join(ROOT, "color-transfer_amd"))
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "import torch, ct_hip\n"
+            "try:\n    ct_hip._conv_scratch(torch.device('cuda', 0))\nexcept Exception as e:\n    print('raised', type(e).__name__)\n"
+            "print('lib loaded', ct_hip._lib is not None)\n") % (ROOT, os.path.join(ROOT, "color-transfer_amd"))
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert "lib loaded True" in p.stdout, (p.stdout, p.stderr[-500:])
