@@ -254,7 +254,9 @@ def test_first_library_use_through_any_entry_cannot_deadlock():
     import subprocess
     import sys
     code = ("import sys; sys.path[:0] = [%r, %r]\n"
-            "import torch, ct_hip\n"
+            "import torch, ct_hip, types\n"
+            "torch.cuda.current_stream = lambda d=None: types.SimpleNamespace(cuda_stream=0)\n"
+            "torch.cuda.is_current_stream_capturing = lambda: False\n"
             "try:\n    ct_hip._conv_scratch(torch.device('cuda', 0))\nexcept Exception as e:\n    print('raised', type(e).__name__)\n"
             "print('lib loaded', ct_hip._lib is not None)\n") % (ROOT, os.path.join(ROOT, "color-transfer_amd"))
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
