@@ -107,16 +107,33 @@ constexpr int kTilePixels = 4 * kWave;
 typedef float float3v __attribute__((ext_vector_type(3)));
 typedef float3v float3u __attribute__((aligned(4)));
 
+// Non-temporal accesses (round 5): every frame of these sweeps is touched exactly once per launch, so its lines need not displace
+// anything in L2 / MALL.  Measured on the two Reinhard sweeps, same box (tools/bench_sweeps.py): statistics 161.5 -> 157.8 us,
+// apply + PSNR 238.6 -> 221.7 us, apply alone 159.0 -> 141.2 us (5.64 TB/s on its two planes).  -DCT_TEMPORAL restores plain accesses.
+#ifndef CT_TEMPORAL
+#define CT_NT_LOAD 1
+#define CT_NT_STORE 1
+#endif
 __device__ __forceinline__ void load_tile(const float *tile, int lane, float (&e)[12]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+#ifdef CT_NT_LOAD
+        const float3v a = __builtin_nontemporal_load(reinterpret_cast<const float3u *>(tile + (j * kWave + lane) * 3));
+#else
         const float3v a = *reinterpret_cast<const float3u *>(tile + (j * kWave + lane) * 3);
+#endif
         e[3 * j] = a.x; e[3 * j + 1] = a.y; e[3 * j + 2] = a.z;
     }
 }
 __device__ __forceinline__ void store_tile(float *tile, int lane, const float (&e)[12]) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<float3u *>(tile + (j * kWave + lane) * 3) = float3v{e[3 * j], e[3 * j + 1], e[3 * j + 2]};
+    for (int j = 0; j < 4; ++j) {
+#ifdef CT_NT_STORE
+        __builtin_nontemporal_store(float3v{e[3 * j], e[3 * j + 1], e[3 * j + 2]}, reinterpret_cast<float3u *>(tile + (j * kWave + lane) * 3));
+#else
+        *reinterpret_cast<float3u *>(tile + (j * kWave + lane) * 3) = float3v{e[3 * j], e[3 * j + 1], e[3 * j + 2]};
+#endif
+    }
 }
 
 __device__ __forceinline__ uint32_t max3u(uint32_t a, uint32_t b, uint32_t c) { return max(max(a, b), c); }      // v_max3_u32

@@ -145,7 +145,7 @@ template <> struct Tile<uint8_t> {
         const uint8_t *q = reinterpret_cast<const uint8_t *>(p) + lane * 12;
         if ((reinterpret_cast<uintptr_t>(p) & 3) == 0) {
             typedef uint32_t u3 __attribute__((ext_vector_type(3)));
-            const u3 v = *reinterpret_cast<const u3 __attribute__((aligned(4))) *>(q);
+            const u3 v = *reinterpret_cast<const u3 __attribute__((aligned(4))) *>(q);     // plain: non-temporal measured 2 % slower here
             r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z;
         } else {
 #pragma unroll
@@ -250,6 +250,15 @@ __device__ __forceinline__ bool fwd_tile(const unsigned char *tab, Scratch *sc, 
 
 // ---- affine map + inverse transform of one parked tile, result stored, squared error against gv accumulated ----------------------
 template <typename T> __device__ __forceinline__ void store_pixel(float *tile, int lane, int q, float r, float g, float b) {
+    // non-temporal only in the float32 layout, where one store instruction of the wave covers 768 contiguous bytes; in the uint8
+    // layout a lane writes its four pixels with four instructions (48-byte lane stride): those need L2 to merge them into lines
+    // (non-temporal there: 48.5 -> 24.5 k pairs/s, round 5)
+#ifdef CT_NT_STORE
+    if constexpr (sizeof(T) == 4) {
+        __builtin_nontemporal_store(float3v{r, g, b}, reinterpret_cast<float3u *>(tile + pixel_of<T>(lane, q) * 3));
+        return;
+    }
+#endif
     *reinterpret_cast<float3u *>(tile + pixel_of<T>(lane, q) * 3) = float3v{r, g, b};
 }
 
