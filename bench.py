@@ -336,6 +336,15 @@ def main():
                 pipelined(20)
                 extra["reinhard_pairs_per_s_with_psnr_two_streams"] = B * pipelined(200)
                 del bufs, two
+            # how much of a step is launch ramp / tail: the same fused call over 8 and 32 pairs (the headline keeps 16)
+            by_pairs = {B: value}
+            for nb in (8, 32):
+                ids = [rank + world * i for i in range(nb)]
+                tb, rb, gb = synth_frames(ids, device)
+                ob, pb = torch.empty_like(tb), torch.zeros((nb, 2), dtype=torch.float64, device=device)
+                by_pairs[nb] = nb * rate(lambda: ct_hip.reinhard_psnr(tb, rb, gb, out=ob, psnr_out=pb), n=100)
+                del tb, rb, gb, ob, pb
+            extra["reinhard_pairs_per_s_with_psnr_by_pairs_per_call"] = by_pairs
             # the one-launch form (csrc/reinhard_persist.hip): float32 frames by name, uint8 frames through the u8 front door
             pr = torch.zeros((B, 2), dtype=torch.float64, device=device)
             extra["reinhard_persist_f32_pairs_per_s_with_psnr"] = B * rate(lambda: ct_hip.reinhard_persist(tgt, ref, gt=gt, out=out, psnr_out=pr), n=100)
