@@ -653,12 +653,10 @@ __global__ void pam_valid_kernel(const float *__restrict__ colpart, int tiles, i
 
 template <int MODE, int TQ>
 static int launch_pam_tq(const PamArgs &a, int N, hipStream_t s, size_t lds) {
-    static size_t attr = 0;
-    if (lds > attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pam_attend_kernel<MODE, TQ>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static DynLdsAttr attr;             // per instantiation, per device
+    {
+        hipError_t e = attr.ensure(reinterpret_cast<const void *>(&pam_attend_kernel<MODE, TQ>), lds);
         if (e != hipSuccess) return (int)e;
-        attr = lds;
     }
     dim3 grid((a.W + TQ - 1) / TQ, a.H, N);
     hipLaunchKernelGGL((pam_attend_kernel<MODE, TQ>), grid, dim3(256), lds, s, a);

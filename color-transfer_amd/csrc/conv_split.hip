@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0) (void)__hip_atomic_exchange(a.sk_flags + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) (void)__hip_atomic_exchange(a.sk_flags + blockIdx.x, a.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (seg_last) {
             // ---- epilogue: lane owns pixels (y0 + wave*RPW + q, x0+nl), channels (r&3)+8(r>>2)+4hl of each 32-tile ----
             const bool take = F16 && seg_k == 2;      // stream-K tail piece: the neighbour's head partial is added below
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a, int tile
                     // workgroups of the launch are resident -- costs a wrong tile and a count in the error word, not a hung queue
                     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                     bool seen;
-                    while (!(seen = __hip_atomic_load(a.sk_flags + (blockIdx.x - 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) &&
+                    while (!(seen = __hip_atomic_load(a.sk_flags + (blockIdx.x - 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.sk_epoch) &&
                            __builtin_amdgcn_s_memrealtime() - t0 < 100000000ull)
                         __builtin_amdgcn_s_sleep(4);
                     if (!seen) {
@@ -776,6 +776,13 @@ static int launch_split(const ConvArgs &a_in, int N, hipStream_t s) {
           (double)((n_tiles + grid - 1) / grid) > 1.08 * rounds)) {
         a.sk_ws = nullptr;
         a.sk_flags = nullptr;
+    } else {
+        // flags carry a per-launch epoch (process-wide counter, never 0).  A replayed graph repeats its epoch; there the
+        // consumer's clearing store is what separates the replays, as before
+        static std::atomic<unsigned int> epoch{0};
+        unsigned int e = epoch.fetch_add(1, std::memory_order_relaxed) + 1u;
+        if (e == 0u) e = epoch.fetch_add(1, std::memory_order_relaxed) + 1u;
+        a.sk_epoch = e;
     }
     hipLaunchKernelGGL((conv_split_kernel<KH, KW, GEN, F16>), dim3(grid), dim3(256), lds, s, a, tiles_x, tiles_y, (int)n_tiles);
     CT_CHECK_LAUNCH();

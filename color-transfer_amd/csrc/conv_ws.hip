@@ -72,7 +72,13 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs a, int n_strip
     constexpr int PIECES = F16 ? 2 : 3;
     constexpr int kWsSlot = PIECES * 2 * kWsCols;
     extern __shared__ uint4 smem16[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, hl = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, nl = lane & 31, hl = lane >> 5;
+    // the wave number in a scalar register: the X / Y order below is then a UNIFORM branch around two separate row loops.  As a
+    // lane-dependent select both orders shared one loop body, and the compiler -- which must assume that either side's loads can
+    // be in flight when the other side starts -- drained the vector memory counter at the head of every step: the wave that
+    // starts with X waited for the requests it had issued just before the barrier (a full memory latency per row step),
+    // the one that starts with Y for the store of the previous X (round 5, tools/prof_conv_ws.py)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int chunk = wave & 3, mt = wave >> 2;         // waves c and c + 4 run on SIMD c
     uint4 *ring = smem16 + chunk * (kWsRing * kWsSlot);                                   // this chunk's input rows
     float *part = reinterpret_cast<float *>(smem16 + kWsChunks * kWsRing * kWsSlot);      // [2][chunk][64][kWsPS]
@@ -137,6 +143,13 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs a, int n_strip
         const int e_co = 8 * wave + e_row;
         const float bias_l = a.bias[grp * 64 + e_co];     // zero padded to 64
         const bool e_ok = (x0 + 4 * e_g) < a.W && e_co < cout_g;
+        // output rows leave through a buffer descriptor over this wave's eight output planes: a store that must not happen
+        // (columns past the image, rows of padding steps, channels past cout -- zero records) gets an out-of-range offset and is
+        // dropped by the hardware.  No branch around the store: the compiler's count of the vector memory operations in flight
+        // stays exact (a store under a branch made every later wait for an input row wait for the store as well)
+        const int e_planes = min(max(cout_g - 8 * wave, 0), 8);
+        const __amdgpu_buffer_rsrc_t out_rs =
+            __builtin_amdgcn_make_buffer_rsrc(out + (size_t)(8 * wave) * plane, 0, (int)((unsigned int)e_planes * uplane * 4u), 0x00020000);
 
         // input rows travel through three register sets: the row staged at the end of step r was requested two steps earlier
         // (one step of distance left the HBM latency exposed: the kernel without its MFMAs took 60 % of the full time)
@@ -165,20 +178,29 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs a, int n_strip
         // interior strips / rows / full chunks need no masks at all (uniform per workgroup and row)
         const bool strip_inside = x0 >= 4 && x0 + 36 <= a.W && c_base + 16 <= a.cin;
         // F16: max |x| of this wave's half of input row y (zeros outside the image) -> rowmax[chunk][mt][idx]
+        // (MFMA and VALU cycles add up on this chip -- DESIGN.md 4.5 -- so every vector instruction of the staging phase costs the
+        // matrix pipe its slot: interior rows of interior strips, the common case, take a mask-free form; round 5)
         auto note_row_max = [&](int idx, int y, const float4 &la, const float4 &lb) {
             if constexpr (F16) {
-                float ma = 1.f, mb = 1.f;
-                if (!(strip_inside && y >= 0 && y < a.H)) row_mask(y, ma, mb);
-                float m = 0.f;
-                if (ma != 0.f) m = fmaxf(fmaxf(fabsf(la.x), fabsf(la.y)), fmaxf(fabsf(la.z), fabsf(la.w)));
-                if (mb != 0.f) m = fmaxf(m, fmaxf(fmaxf(fabsf(lb.x), fabsf(lb.y)), fmaxf(fabsf(lb.z), fabsf(lb.w))));
+                float m;
+                if (strip_inside && y >= 0 && y < a.H) {            // uniform per workgroup and row
+                    m = fmaxf(fmaxf(fmaxf(fabsf(la.x), fabsf(la.y)), fabsf(la.z)), fmaxf(fmaxf(fabsf(la.w), fabsf(lb.x)), fabsf(lb.y)));
+                    m = fmaxf(fmaxf(m, fabsf(lb.z)), fabsf(lb.w));
+                } else {
+                    float ma = 1.f, mb = 1.f;
+                    row_mask(y, ma, mb);
+                    m = 0.f;
+                    if (ma != 0.f) m = fmaxf(fmaxf(fabsf(la.x), fabsf(la.y)), fmaxf(fabsf(la.z), fabsf(la.w)));
+                    if (mb != 0.f) m = fmaxf(m, fmaxf(fmaxf(fabsf(lb.x), fabsf(lb.y)), fmaxf(fabsf(lb.z), fabsf(lb.w))));
+                }
                 m = wave_max_nonneg(m);
                 if (lane == 0) rowmax[(chunk * 2 + mt) * 4 + idx] = m;
             }
         };
         auto stage_row = [&](int slot, int y, const float4 &la, const float4 &lb, int max_idx) {   // registers -> pieces -> LDS slot
+            const bool plain = strip_inside && y >= 0 && y < a.H;  // uniform: no masks at all
             float ma = 1.f, mb = 1.f;
-            if (!(strip_inside && y >= 0 && y < a.H)) row_mask(y, ma, mb);
+            if (!plain) row_mask(y, ma, mb);
             float scale = 1.f;
             if constexpr (F16) {
                 // the row's scale: both halves' maxima were written at least one barrier ago.  2^ex * max in [2^11, 2^12).
@@ -196,23 +218,37 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs a, int n_strip
 #endif
                 const int kh2 = u_cp >> 2, wsel = u_cp & 3;
                 unsigned int *d = reinterpret_cast<unsigned int *>(ring + slot * kWsSlot) + ((kh2 * kWsCols + 4 * u_grp) * 4 + wsel);
-                const float xa[4] = {ma != 0.f ? la.x : 0.f, ma != 0.f ? la.y : 0.f, ma != 0.f ? la.z : 0.f, ma != 0.f ? la.w : 0.f};
-                const float xb[4] = {mb != 0.f ? lb.x : 0.f, mb != 0.f ? lb.y : 0.f, mb != 0.f ? lb.z : 0.f, mb != 0.f ? lb.w : 0.f};
+                auto pieces = [&](const float (&xa)[4], const float (&xb)[4]) {
 #pragma unroll
-                for (int px = 0; px < 4; ++px) {
-                    if constexpr (F16) {
-                        const float sa = xa[px] * scale, sb = xb[px] * scale;
-                        const f16x2 h = cvt_pk_f16(sa, sb);
-                        const f16x2 l = cvt_pk_f16(sa - (float)h.x, sb - (float)h.y);
-                        d[px * 4] = __builtin_bit_cast(unsigned int, h);
-                        d[(2 * kWsCols + px) * 4] = __builtin_bit_cast(unsigned int, l);
-                    } else {
-                        unsigned int hw, mw, lw;
-                        split3x2(xa[px], xb[px], hw, mw, lw);
-                        d[px * 4] = hw;
-                        d[(2 * kWsCols + px) * 4] = mw;
-                        d[(4 * kWsCols + px) * 4] = lw;
+                    for (int px = 0; px < 4; ++px) {
+                        if constexpr (F16) {
+                            const float sa = xa[px] * scale, sb = xb[px] * scale;
+                            const f16x2 h = cvt_pk_f16(sa, sb);
+                            // lo = s - float(hi), exactly, in ONE instruction per value: v_fma_mix_f32 reads the fp16 half directly
+                            // (convert + subtract were two; the compiler does not form it across the opaque v_cvt_pk_f16_f32)
+                            float da, db;
+                            const unsigned int hu = __builtin_bit_cast(unsigned int, h);
+                            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(da) : "v"(hu), "v"(sa));
+                            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(db) : "v"(hu), "v"(sb));
+                            const f16x2 l = cvt_pk_f16(da, db);
+                            d[px * 4] = hu;
+                            d[(2 * kWsCols + px) * 4] = __builtin_bit_cast(unsigned int, l);
+                        } else {
+                            unsigned int hw, mw, lw;
+                            split3x2(xa[px], xb[px], hw, mw, lw);
+                            d[px * 4] = hw;
+                            d[(2 * kWsCols + px) * 4] = mw;
+                            d[(4 * kWsCols + px) * 4] = lw;
+                        }
                     }
+                };
+                if (plain) {
+                    const float xa[4] = {la.x, la.y, la.z, la.w}, xb[4] = {lb.x, lb.y, lb.z, lb.w};
+                    pieces(xa, xb);
+                } else {
+                    const float xa[4] = {ma != 0.f ? la.x : 0.f, ma != 0.f ? la.y : 0.f, ma != 0.f ? la.z : 0.f, ma != 0.f ? la.w : 0.f};
+                    const float xb[4] = {mb != 0.f ? lb.x : 0.f, mb != 0.f ? lb.y : 0.f, mb != 0.f ? lb.z : 0.f, mb != 0.f ? lb.w : 0.f};
+                    pieces(xa, xb);
                 }
             }
         };
@@ -283,12 +319,14 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs a, int n_strip
         };
         auto reduce_store = [&](int r) {
 #ifdef CT_WS_ABL_NOSTORE
-            if (e_ok && r >= 0 && r < rows && rvv[0] == 123.456f)
+            const bool ok = e_ok && r >= 0 && r < rows && rvv[0] == 123.456f;
 #else
-            if (e_ok && r >= 0 && r < rows)                  // the first X has no row to finish; the last steps may be padding
+            const bool ok = e_ok && r >= 0 && r < rows;      // the first X has no row to finish; the last steps may be padding
 #endif
-                *reinterpret_cast<float4 *>(out + (unsigned int)e_co * uplane + (unsigned int)((y0 + r) * a.W + x0 + 4 * e_g)) =
-                    make_float4(rvv[0], rvv[1], rvv[2], rvv[3]);
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 v = {__float_as_uint(rvv[0]), __float_as_uint(rvv[1]), __float_as_uint(rvv[2]), __float_as_uint(rvv[3])};
+            const unsigned int off = ok ? ((unsigned int)e_row * uplane + (unsigned int)((y0 + r) * a.W + x0 + 4 * e_g)) * 4u : 0xffffffffu;
+            __builtin_amdgcn_raw_buffer_store_b128(v, out_rs, (int)off, 0, 0);
         };
         auto reduce_row = [&](int r, const float4 &rv) { reduce_issue(r); reduce_compute(rv); reduce_store(r); };
 #ifdef CT_WS_ABL_NOREDUCE
@@ -380,6 +418,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs a, int n_strip
                 if (ky == 1) reduce_store(r - 1);
                 if constexpr (F16) __builtin_amdgcn_sched_barrier(0);
             }
+            WS_STAMP(6);
             // lane owns column nl, output channels 32 mt + (i & 3) + 8 (i >> 2) + 4 hl
             float *pw = part + (((r & 1) * kWsChunks + chunk) * 64 + 32 * mt) * kWsPS + nl;
             float unscale = 1.f;
@@ -400,7 +439,9 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs a, int n_strip
             constexpr int SET = decltype(set_c)::value;      // r % 3
             fetch_skip(r + 1, rq[(SET + 1) % 3]);                  // consumed by reduce(r+1) inside X(r+2): more than a step from now
             fetch_row(y0 + r + 4, qa[(SET + 2) % 3], qb[(SET + 2) % 3]);
+            WS_STAMP(3);
             note_row_max((r + 1) & 1, y0 + r + 3, qa[(SET + 1) % 3], qb[(SET + 1) % 3]);   // F16: the row staged in Y(r+1)
+            WS_STAMP(5);
             stage_row((r + 3) & (kWsRing - 1), y0 + r + 2, qa[SET], qb[SET], r & 1);   // the slot of input row y0+r-1 is free since X(r-1)
         };
         // The two waves of a SIMD run the phases of a step in opposite order -- while one of them is in X (27 or 54 MFMAs) the
@@ -409,20 +450,24 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs a, int n_strip
         // phase of the same step: X(r) reads ring slots r .. r+2 and the partial sums of step r-1 and writes the partial sums
         // r & 1 (last read in step r-1); Y(r) writes ring slot r+3 (last read in step r-1), its exponent, and the row
         // maximum (r+1) & 1, and reads the maxima r & 1 (written in step r-1).
-        auto step = [&](int r, auto set_c) {
+        auto step = [&](int r, auto set_c, auto mt_c) {
             WS_STAMP(4);
-            if (mt == 0) { phase_x_full(r, set_c); WS_STAMP(0); phase_y(r, set_c); WS_STAMP(2); }
+            if constexpr (decltype(mt_c)::value == 0) { phase_x_full(r, set_c); WS_STAMP(0); phase_y(r, set_c); WS_STAMP(2); }
             else { phase_y(r, set_c); WS_STAMP(2); phase_x_full(r, set_c); WS_STAMP(0); }
             __syncthreads();
             WS_STAMP(1);
         };
         const int steps = (rows + 2) / 3 * 3;
+        auto row_loop = [&](auto mt_c) {
 #pragma unroll 1
-        for (int r = 0; r < steps; r += 3) {
-            step(r, std::integral_constant<int, 0>());
-            step(r + 1, std::integral_constant<int, 1>());
-            step(r + 2, std::integral_constant<int, 2>());
-        }
+            for (int r = 0; r < steps; r += 3) {
+                step(r, std::integral_constant<int, 0>(), mt_c);
+                step(r + 1, std::integral_constant<int, 1>(), mt_c);
+                step(r + 2, std::integral_constant<int, 2>(), mt_c);
+            }
+        };
+        if (mt == 0) row_loop(std::integral_constant<int, 0>());       // uniform: mt lives in a scalar register
+        else row_loop(std::integral_constant<int, 1>());
         reduce_row(steps - 1, rq[2]);                        // steps % 3 == 0: the skip row of the last step sits in set 2
         __syncthreads();      // the partial-sum tiles of the last rows are read before the next item overwrites them
     }
@@ -446,7 +491,7 @@ int conv_ws(const ConvArgs &a, int N, bool gen, hipStream_t s) {
     if (a.prof != nullptr) return 1;
 #endif
     if ((!enabled && !a.f16) || a.in2 != nullptr || a.cin <= 32 || a.cin > 64) return 1;
-    if ((unsigned long long)a.H * (unsigned long long)a.W * 64ull >= (1ull << 32)) return 1;     // the kernel indexes a 64-channel image with 32 bits: the tile kernel takes larger ones
+    if ((unsigned long long)a.H * (unsigned long long)a.W * 64ull >= (1ull << 32)) return 1;     // the kernel indexes a 64-channel image with 32 bits (and eight output planes with 32-bit BYTE offsets): the tile kernel takes larger ones
     const int n_strips = (a.W + kWsTW - 1) / kWsTW;
     // row segments: the split that minimises the row steps of the busiest workgroup (32 workgroups per XCD sweep the bands
     // of that XCD; a segment costs its rows + 2 halo rows of staging)
@@ -481,10 +526,10 @@ int conv_ws(const ConvArgs &a, int N, bool gen, hipStream_t s) {
     static const kern_t kerns[8] = {conv_ws_kernel<0, false>, conv_ws_kernel<1, false>, conv_ws_kernel<2, false>, conv_ws_kernel<3, false>,
                                     conv_ws_kernel<0, true>,  conv_ws_kernel<1, true>,  conv_ws_kernel<2, true>,  conv_ws_kernel<3, true>};
     const kern_t kern = kerns[variant];
-    static bool attr_set[8] = {false, false, false, false, false, false, false, false};
-    if (!attr_set[variant]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set[variant] = true;
+    static DynLdsAttr attr[8];          // per kernel variant, per device
+    {
+        hipError_t e = attr[variant].ensure(reinterpret_cast<const void *>(kern), lds);
+        if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * kWsWaves), lds, s, b, n_strips, seg, n_seg, (int)n_items);
     CT_CHECK_LAUNCH();

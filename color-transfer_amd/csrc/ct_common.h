@@ -1,5 +1,6 @@
 // ct_common.h -- shared launch / reduction helpers for libct_hip.so (gfx950 only).
 #pragma once
+#include <atomic>
 #include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -27,6 +28,28 @@ inline int blocks_per_image(int64_t n_chunks, int n_images) {
     if (want < 1) want = 1;
     return (int)want;
 }
+
+// ---- per-device launch state ----------------------------------------------------------------------------------------------------
+// Function attributes and the CU count belong to a DEVICE: a process that drives a second GPU must set them there as well.
+constexpr int kMaxDevices = 64;
+inline int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    return dev >= 0 && dev < kMaxDevices ? dev : 0;
+}
+// hipFuncAttributeMaxDynamicSharedMemorySize of one kernel, raised once per device (one static instance per kernel symbol;
+// safe from concurrent host threads: the worst case is the same attribute set twice)
+struct DynLdsAttr {
+    std::atomic<int> have[kMaxDevices];
+    hipError_t ensure(const void *fn, size_t bytes) {
+        const int dev = current_device();
+        if (have[dev].load(std::memory_order_acquire) >= (int)bytes) return hipSuccess;
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e == hipSuccess) have[dev].store((int)bytes, std::memory_order_release);
+        else (void)hipGetLastError();
+        return e;
+    }
+};
 
 #define CT_CHECK_LAUNCH()                           \
     do {                                            \

@@ -33,6 +33,8 @@ struct ConvArgs {
     int rows_c0 = 0;            // channels rows_c0 .. rows_c0 + cout (multiples of 4); no residual / clamp in this mode
     float *sk_ws = nullptr;         // split kernel, F16 form: stream-K scratch (partial tiles, one 64 KiB slot per workgroup), or NULL
     unsigned int *sk_flags = nullptr;   // ... and its flags (one per workgroup; zero between launches)
+    unsigned int sk_epoch = 1;      // ... the value a producer of THIS launch publishes (non-zero, new for every launch: a flag left behind
+                                    //     by a producer that came too late for its consumer cannot satisfy the next launch's wait)
 };
 
 struct GConvArgs {

@@ -179,10 +179,10 @@ static int fft_pass(float2 *data, int hp, int wp, int planes, int sign, hipStrea
     const long long grid = groups * planes;
     if (grid > 0x7fffffffLL) return CT_E_BADARG;
     auto kern = fft_lines_kernel<COLS>;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kFftLdsBudget);
-        attr = true;
+    static DynLdsAttr attr;             // per instantiation (COLS), per device
+    {
+        hipError_t e = attr.ensure(reinterpret_cast<const void *>(kern), kFftLdsBudget);
+        if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kFftThreads), lds, s, a);
     CT_CHECK_LAUNCH();

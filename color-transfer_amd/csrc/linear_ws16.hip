@@ -320,13 +320,10 @@ int ct_linear_ws16_f32(const float *x, const float *x2, int k1, const void *wp16
     if (nt > 0x7fffffffLL) return CT_E_BADARG;
     a.n_tiles = (int)nt; a.act = act;
     a.ln_g = ln_gamma; a.ln_b = ln_beta; a.ln_res = ln_residual;
-    static const bool attr = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(ct::linear_ws16_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   ct::w16_img(8) * 16 + 32768) == hipSuccess &&
-               hipFuncSetAttribute(reinterpret_cast<const void *>(ct::linear_ws16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   ct::w16_img(4) * 16 + 32768) == hipSuccess;
-    }();
-    if (!attr) return CT_E_BADARG;
+    static ct::DynLdsAttr attr8, attr4;  // per device
+    if (attr8.ensure(reinterpret_cast<const void *>(ct::linear_ws16_kernel<8>), ct::w16_img(8) * 16 + 32768) != hipSuccess ||
+        attr4.ensure(reinterpret_cast<const void *>(ct::linear_ws16_kernel<4>), ct::w16_img(4) * 16 + 32768) != hipSuccess)
+        return CT_E_BADARG;
     if (slab) hipLaunchKernelGGL(ct::linear_ws16_kernel<4>, dim3(256), dim3(512), ct::w16_img(4) * 16 + 32768, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(ct::linear_ws16_kernel<8>, dim3(256), dim3(512), ct::w16_img(8) * 16 + 32768, (hipStream_t)stream, a);
     CT_CHECK_LAUNCH();

@@ -291,11 +291,8 @@ int ct_regrain_f64(const double *img_in, const double *img_col, double *out, int
     if (!img_in || !img_col || !out || !nbits || height < 1 || width < 1 || n_nbits < 1 || n_nbits > kRgMaxLevels) return CT_E_BADARG;
     if (!ws || (reinterpret_cast<uintptr_t>(ws) & 15) || ws_bytes < ct_regrain_workspace_bytes(height, width)) return CT_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    static const bool attr_set = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(rg_sweepk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)(7 * kRgMaxRegion * sizeof(double))) == hipSuccess;
-    }();
-    (void)attr_set;
+    static DynLdsAttr attr;             // per device
+    if (attr.ensure(reinterpret_cast<const void *>(rg_sweepk_kernel), 7 * kRgMaxRegion * sizeof(double)) != hipSuccess) return CT_E_BADARG;
     RgLevel lv[kRgMaxLevels];
     const int n = rg_levels(height, width, n_nbits, lv);
     double *p = reinterpret_cast<double *>(ws);

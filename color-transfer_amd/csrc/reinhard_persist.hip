@@ -728,13 +728,7 @@ __global__ __launch_bounds__(256) void psnr_finish_persist_kernel(const double *
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------------
-constexpr int kMaxDevices = 64;
 constexpr int kMaxGrid = 63 * kShards;            // the arrival / invalid counts of a shard record are 6 bits wide
-static int current_device() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
-    return dev >= 0 && dev < kMaxDevices ? dev : 0;
-}
 // workgroups of the launch = CUs of the CURRENT device (cached per device), or CT_HIP_PERSIST_WGS (tuning / a device with
 // masked CUs); 0 = this device cannot take the launch (more workgroups than the hand-off's count fields hold)
 static int grid_size() {
@@ -800,12 +794,11 @@ int launch(const T *target, const T *reference, const T *gt, float *out, double 
     constexpr int waves = kMaxWaves;
     void (*kern)(const Args) = gt ? reinhard_persist_kernel<T, true, kMaxWaves> : reinhard_persist_kernel<T, false, kMaxWaves>;
     // function attributes are per device: cached per (device, instantiation of this template (T) x gt)
-    static std::atomic<bool> attr_done[kMaxDevices][2];
+    static DynLdsAttr attr[2];
     const int dev = current_device();
-    if (!attr_done[dev][gt ? 1 : 0].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax);
+    {
+        hipError_t e = attr[gt ? 1 : 0].ensure(reinterpret_cast<const void *>(kern), kLdsMax);
         if (e != hipSuccess) return (int)e;
-        attr_done[dev][gt ? 1 : 0].store(true, std::memory_order_release);
     }
     // Two persistent launches must not share the GPU: each needs every one of its workgroups resident (one per CU, the CU's LDS to
     // itself), so a second one on another stream would leave both with workgroups that cannot start until the other ends -- a

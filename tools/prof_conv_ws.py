@@ -26,10 +26,11 @@ for i in range(4):
     ct_hip.conv2d(x, wp, bp, C, 3, act=1, residual=x, out=out)
 e1.record(); torch.cuda.synchronize()
 p = prof.cpu().numpy().astype(np.float64).reshape(256, 8, 8)
-names = ["X (reduce r-1, MFMAs, partial sums)", "barrier (one per step)", "Y (requests, row max, staging)", "-", "other (prologue, weights)"]
+names = ["X: partial sums -> LDS", "barrier (one per step)", "Y: staging (scale, pieces -> LDS)", "Y: requests (skip row, input row)", "other (prologue, weights)",
+         "Y: row maximum", "X: reduce r-1 + MFMAs"]
 print("kernel %.1f us (stamped build, ws16=%s); s_memtime ticks per wave, median over workgroups" % (e0.elapsed_time(e1) * 1e3, ct_hip.conv_ws16()))
 for w in (0, 4):
-    q = p[:, w, :5]
+    q = p[:, w, :7]
     tot = q.sum(axis=1)
     print("  wave %d (mt = %d)" % (w, w // 4))
     for i, n in enumerate(names):
