@@ -381,7 +381,7 @@ class GMFlow(nn.Module):
         return h, mask, delta
 
     @torch.no_grad()
-    def _unimatch(self, img0, img1, num_reg_refine, dbg):                # unimatch.py:98-370 (fixed configuration)
+    def _unimatch(self, img0, img1, num_reg_refine, dbg, bidir=True):    # unimatch.py:98-370 (fixed configuration)
         B = img0.shape[0]
         plane = img0.shape[2] * img0.shape[3]
         both = torch.cat((ct_hip.eltwise(3, img0, plane=plane), ct_hip.eltwise(3, img1, plane=plane)), dim=0)
@@ -391,7 +391,7 @@ class GMFlow(nn.Module):
         flow = None
         for scale, (splits, corr_r, prop_r) in enumerate(((2, -1, -1), (8, 4, 1))):
             f0, f1 = feats[scale][:B], feats[scale][B:]
-            if scale > 0:
+            if scale > 0 and bidir:
                 f0, f1 = torch.cat((f0, f1), dim=0), torch.cat((f1, f0), dim=0)
             b, c, h, w = f0.shape
             f0_ori, f1_ori = f0, f1
@@ -405,16 +405,19 @@ class GMFlow(nn.Module):
             if corr_r == -1:                                              # matching.py:10-39, both directions
                 grid = _coords_tokens(b, h, w, f0.device)
                 fwd = ct_hip.attention_tokens(t0, t1, grid)
-                bwd = ct_hip.attention_tokens(t1, t0, grid)
-                corresp = torch.cat((fwd, bwd), dim=0)
-                grid2 = torch.cat((grid, grid), dim=0)
+                if bidir:
+                    bwd = ct_hip.attention_tokens(t1, t0, grid)
+                    corresp = torch.cat((fwd, bwd), dim=0)
+                    grid2 = torch.cat((grid, grid), dim=0)
+                else:                                                     # matching.py:27-39 without the transposed half
+                    corresp, grid2 = fwd, grid
                 pred = _nchw(ct_hip.eltwise(0, corresp, ct_hip.eltwise(4, grid2, s0=-1.0)), h, w)
             else:
                 pred = ct_hip.local_corr_softmax(t0, t1, h, w, corr_r)
             flow = ct_hip.eltwise(0, flow, pred) if flow is not None else pred
             if dbg is not None:
                 dbg["flow_match_s%d" % scale] = flow
-            if scale == 0:
+            if scale == 0 and bidir:
                 t0 = torch.cat((t0, t1), dim=0)
             prop = self.feature_flow_attn                                 # attention.py:188-256
             qtok = _lin(prop.q_proj, t0)
@@ -447,10 +450,13 @@ class GMFlow(nn.Module):
     def forward(self, img0, img1, padding_factor=32, inference_size=None, attn_type="swin", attn_splits_list=(2, 8),
                 corr_radius_list=(-1, 4), prop_radius_list=(-1, 1), num_reg_refine=6, pred_bidir_flow=False,
                 pred_bwd_flow=False, pred_flow_viz=False, fwd_bwd_consistency_check=False, dbg=None, **kwargs):
-        """unimatch/__init__.py:60-167.  Only pred_bidir_flow=True with the default lists is implemented."""
-        if (not pred_bidir_flow or pred_bwd_flow or pred_flow_viz or attn_type != "swin" or tuple(attn_splits_list) != (2, 8)
+        """unimatch/__init__.py:60-167 with the default split / radius lists: DMSCT's call (pred_bidir_flow=True, occlusion masks)
+        and the one-direction forms (pred_bidir_flow=False; pred_bwd_flow swaps the frames, :117-118).  No flow visualisation."""
+        if (pred_flow_viz or attn_type != "swin" or tuple(attn_splits_list) != (2, 8)
                 or tuple(corr_radius_list) != (-1, 4) or tuple(prop_radius_list) != (-1, 1)):
-            raise NotImplementedError("GMFlow on HIP implements DMSCT's call: pred_bidir_flow=True, default split/radius lists")
+            raise NotImplementedError("GMFlow on HIP implements the default split / radius lists, without pred_flow_viz")
+        if fwd_bwd_consistency_check and not pred_bidir_flow:
+            raise AssertionError("fwd_bwd_consistency_check needs pred_bidir_flow (unimatch/__init__.py:85-86)")
         if not img0.is_cuda:
             raise ct_hip.CtHipError("GMFlow runs on the GPU only (no CPU fallback)")
         img0, img1 = img0.float().contiguous(), img1.float().contiguous()
@@ -464,11 +470,15 @@ class GMFlow(nn.Module):
         resize = size[0] != ori[0] or size[1] != ori[1]
         if resize:
             img0, img1 = ct_hip.bilinear_resize(img0, size), ct_hip.bilinear_resize(img1, size)
-        flow = self._unimatch(img0, img1, num_reg_refine, dbg)
+        if pred_bwd_flow:
+            img0, img1 = img1, img0
+        flow = self._unimatch(img0, img1, num_reg_refine, dbg, bidir=bool(pred_bidir_flow))
         if resize:
             flow = ct_hip.bilinear_resize(flow, ori, ori[1] / size[1], ori[0] / size[0])
         if transpose:
             flow = flow.transpose(-2, -1).contiguous()
+        if not pred_bidir_flow:
+            return {"flow": flow}
         fwd, bwd = flow[::2].contiguous(), flow[1::2].contiguous()
         res = {"flow": fwd, "flow_bwd": bwd}
         if fwd_bwd_consistency_check:

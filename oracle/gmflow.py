@@ -190,13 +190,15 @@ def self_attn_propagation(sd, f0, flow, local_radius):             # attention.p
 
 
 # ---- unimatch/matching.py -------------------------------------------------------------------------------------
-def global_correlation_softmax_bidir(f0, f1):                      # matching.py:10-39 with pred_bidir_flow=True
+def global_correlation_softmax_bidir(f0, f1, bidir=True):          # matching.py:10-39 (pred_bidir_flow: both directions stacked)
     b, c, h, w = f0.shape
     corr = torch.matmul(f0.view(b, c, -1).permute(0, 2, 1), f1.view(b, c, -1)) / c ** 0.5
-    corr = torch.cat((corr, corr.permute(0, 2, 1)), dim=0)
-    grid = coords_grid(2 * b, h, w, f0.dtype)
+    if bidir:
+        corr = torch.cat((corr, corr.permute(0, 2, 1)), dim=0)
+    nb = corr.shape[0]
+    grid = coords_grid(nb, h, w, f0.dtype)
     prob = F.softmax(corr, dim=-1)
-    corresp = torch.matmul(prob, grid.view(2 * b, 2, -1).permute(0, 2, 1)).view(2 * b, h, w, 2).permute(0, 3, 1, 2)
+    corresp = torch.matmul(prob, grid.view(nb, 2, -1).permute(0, 2, 1)).view(nb, h, w, 2).permute(0, 3, 1, 2)
     return corresp - grid
 
 
@@ -260,7 +262,7 @@ def basic_update_block(sd, net, inp, corr, flow, want_mask):       # reg_refine.
 
 
 # ---- unimatch/unimatch.py + __init__.py ---------------------------------------------------------------------------
-def unimatch_flow_bidir(sd, img0, img1, num_reg_refine=6, dbg=None):   # unimatch.py:98-370 for the fixed configuration
+def unimatch_flow_bidir(sd, img0, img1, num_reg_refine=6, dbg=None, bidir=True):   # unimatch.py:98-370 for the fixed configuration
     dtype = img0.dtype
     sd = {k: v.to(dtype) for k, v in sd.items()}
     mean = torch.tensor([0.485, 0.456, 0.406], dtype=dtype).view(1, 3, 1, 1)
@@ -273,7 +275,7 @@ def unimatch_flow_bidir(sd, img0, img1, num_reg_refine=6, dbg=None):   # unimatc
     flow = None
     for scale, (splits, corr_r, prop_r) in enumerate(((2, -1, -1), (8, 4, 1))):
         f0, f1 = f0l[scale], f1l[scale]
-        if scale > 0:
+        if scale > 0 and bidir:
             f0, f1 = torch.cat((f0, f1), dim=0), torch.cat((f1, f0), dim=0)         # unimatch.py:142-144
         f0_ori, f1_ori = f0, f1
         if scale > 0:
@@ -284,13 +286,13 @@ def unimatch_flow_bidir(sd, img0, img1, num_reg_refine=6, dbg=None):   # unimatc
         if dbg is not None:
             dbg["tf0_s%d" % scale] = f0
         if corr_r == -1:
-            pred = global_correlation_softmax_bidir(f0, f1)                         # :208
+            pred = global_correlation_softmax_bidir(f0, f1, bidir)                  # :208
         else:
             pred = local_correlation_softmax(f0, f1, corr_r)                        # :215
         flow = flow + pred if flow is not None else pred                            # :222
         if dbg is not None:
             dbg["flow_match_s%d" % scale] = flow
-        if scale == 0:
+        if scale == 0 and bidir:
             f0 = torch.cat((f0, f1), dim=0)                                         # :237
         flow = self_attn_propagation(sd, f0, flow, prop_r)                          # :239-242
         if dbg is not None:
@@ -319,7 +321,9 @@ def derive_matcher_inference_size(shape, max_area=500 * 900, padding_factor=32):
     return max_size if size[0] * size[1] > max_size[0] * max_size[1] else size
 
 
-def gmflow_forward(sd, img0, img1, inference_size, num_reg_refine=6, dbg=None):   # unimatch/__init__.py:60-167 (bidir + occlusion)
+def gmflow_forward(sd, img0, img1, inference_size, num_reg_refine=6, dbg=None, pred_bidir_flow=True, pred_bwd_flow=False):
+    """unimatch/__init__.py:60-167: DMSCT's call (bidirectional + occlusion masks) by default; pred_bidir_flow=False is the
+    one-direction form (:117-118 swaps the frames for pred_bwd_flow)"""
     transpose = img0.shape[-2] > img0.shape[-1]
     if transpose:
         img0, img1 = img0.transpose(-2, -1), img1.transpose(-2, -1)
@@ -328,12 +332,16 @@ def gmflow_forward(sd, img0, img1, inference_size, num_reg_refine=6, dbg=None): 
     if resize:
         img0 = F.interpolate(img0, size=list(inference_size), mode="bilinear", align_corners=True)
         img1 = F.interpolate(img1, size=list(inference_size), mode="bilinear", align_corners=True)
-    flow = unimatch_flow_bidir(sd, img0, img1, num_reg_refine, dbg)
+    if pred_bwd_flow:
+        img0, img1 = img1, img0
+    flow = unimatch_flow_bidir(sd, img0, img1, num_reg_refine, dbg, bidir=pred_bidir_flow)
     if resize:
         flow = F.interpolate(flow, size=list(ori), mode="bilinear", align_corners=True)
         flow = torch.stack([flow[:, 0] * ori[-1] / inference_size[-1], flow[:, 1] * ori[-2] / inference_size[-2]], dim=1)
     if transpose:
         flow = flow.transpose(-2, -1)
+    if not pred_bidir_flow:
+        return {"flow": flow}
     fwd, bwd = flow[::2], flow[1::2]
     fwd_occ, bwd_occ = forward_backward_consistency_check(fwd, bwd)
     return {"flow": fwd, "flow_bwd": bwd, "fwd_occ": fwd_occ.unsqueeze(1), "bwd_occ": bwd_occ.unsqueeze(1)}

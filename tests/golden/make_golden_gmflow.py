@@ -66,6 +66,26 @@ def main():
         print(tag, "inference size", size, "|flow| mean %.3f max %.3f" % (np.abs(res["flow"]).mean(), np.abs(res["flow"]).max()),
               "occ frac %.3f" % res["fwd_occ"].mean())
     np.savez_compressed(os.path.join(OUT, "gmflow_small.npz"), torch=torch.__version__, **fix)
+    # the one-direction call forms of the same wrapper (unimatch/__init__.py:60-67: pred_bidir_flow=False, pred_bwd_flow), same
+    # state and pairs; only the stages that differ from the bidirectional run are kept (gmflow_uni.npz)
+    uni = {}
+    for tag, (h, w), seed in (("a", (135, 240), 1), ("b", (96, 128), 2)):
+        img0, img1 = test_pair(seed, h, w)
+        size = derive_matcher_inference_size((1, 3, h, w))
+        for name, kw in (("fwd", {}), ("bwd", {"pred_bwd_flow": True})):
+            cap = {"prop_in": [], "prop_out": []}
+            hooks = [model.feature_flow_attn.register_forward_pre_hook(lambda m, i: cap["prop_in"].append(i[1].detach().clone())),
+                     model.feature_flow_attn.register_forward_hook(lambda m, i, o: cap["prop_out"].append(o.detach().clone()))]
+            with torch.no_grad():
+                res = model(img0, img1, inference_size=size, pred_bidir_flow=False, **kw)
+            for hk in hooks:
+                hk.remove()
+            assert set(res.keys()) == {"flow"}
+            uni["%s/%s/flow" % (tag, name)] = res["flow"].numpy()
+            uni["%s/%s/flow_match_s0" % (tag, name)] = cap["prop_in"][0].numpy()
+            uni["%s/%s/flow_prop_s1" % (tag, name)] = cap["prop_out"][1].numpy()
+            print(tag, name, "one direction: flow", res["flow"].shape, "|flow| mean %.3f" % np.abs(res["flow"]).mean())
+    np.savez_compressed(os.path.join(OUT, "gmflow_uni.npz"), torch=torch.__version__, **uni)
     print("wrote gmflow goldens:", sum(int(np.prod(s)) for s in shapes), "parameters,", len(names), "tensors")
 
 

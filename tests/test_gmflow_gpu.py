@@ -96,7 +96,41 @@ def test_gmflow_rejects_other_configurations(golden_dir):
     m = GMFlow().cuda()
     x = torch.rand(1, 3, 64, 64).cuda()
     with pytest.raises(NotImplementedError):
-        m(x, x)                                    # pred_bidir_flow=False is not DMSCT's call
+        m(x, x, pred_flow_viz=True)                # host-side visualisation is not part of the path
+    with pytest.raises(NotImplementedError):
+        m(x, x, attn_splits_list=(2,), corr_radius_list=(-1,), prop_radius_list=(-1,))
+    with pytest.raises(AssertionError):
+        m(x, x, fwd_bwd_consistency_check=True)    # the reference asserts pred_bidir_flow there too (unimatch/__init__.py:85-86)
+
+
+@pytest.mark.parametrize("tag,hw,seed", [("a", (135, 240), 1), ("b", (96, 128), 2)])
+def test_gmflow_one_direction_vs_reference(golden_dir, tag, hw, seed, conv_mode):
+    """The wrapper's other call forms (unimatch/__init__.py:60-67): pred_bidir_flow=False and pred_bwd_flow=True, against runs of
+    the real reference on the same state and pairs (tests/golden/make_golden_gmflow.py -> gmflow_uni.npz); same per-stage bounds
+    as the bidirectional call."""
+    from oracle.gmflow import derive_matcher_inference_size
+    g = _g(golden_dir)
+    u = np.load(os.path.join(golden_dir, "gmflow_uni.npz"), allow_pickle=False)
+    m = build(g)
+    img0, img1 = make_pair(seed, *hw)
+    size = derive_matcher_inference_size((1, 3) + hw)
+    bound = STAGE_BOUNDS[conv_mode]
+    for name, kw in (("fwd", {}), ("bwd", {"pred_bwd_flow": True})):
+        dbg = {}
+        res = m(img0.cuda(), img1.cuda(), inference_size=size, pred_bidir_flow=False, dbg=dbg, **kw)
+        assert set(res.keys()) == {"flow"} and tuple(res["flow"].shape) == (1, 2) + hw
+        for stage, key, b in (("global match", "flow_match_s0", bound["global match"]), ("propagation s1", "flow_prop_s1", bound["propagation s1"])):
+            err = float(np.abs(dbg[key].cpu().numpy().astype(np.float64) - u["%s/%s/%s" % (tag, name, key)]).max())
+            print("[gmflow %s %s, %s convs] %-15s %.2e (%.0e)" % (tag, name, conv_mode, stage, err, b))
+            assert err <= b, (name, stage, err)
+        err = float(np.abs(res["flow"].cpu().numpy().astype(np.float64) - u["%s/%s/flow" % (tag, name)]).max())
+        print("[gmflow %s %s, %s convs] %-15s %.2e (%.0e)" % (tag, name, conv_mode, "flow", err, bound["flow"]))
+        assert err <= bound["flow"], (name, err)
+    # the forward flow of the one-direction call is the forward half of the bidirectional one: the same kernels on the same
+    # samples, independent of the batch position
+    r2 = m(img0.cuda(), img1.cuda(), inference_size=size, pred_bidir_flow=True)
+    r1 = m(img0.cuda(), img1.cuda(), inference_size=size, pred_bidir_flow=False)
+    assert float((r2["flow"] - r1["flow"]).abs().max()) <= 2 * bound["flow"]
 
 
 def test_dmsct_glue_vs_oracle(golden_dir):

@@ -47,6 +47,24 @@ def test_oracle_vs_reference(golden_dir, tag, hw, seed):
     assert agree > 0.995
 
 
+@pytest.mark.parametrize("tag,hw,seed", [("b", (96, 128), 2)])
+def test_oracle_one_direction_vs_reference(golden_dir, tag, hw, seed):
+    """pred_bidir_flow=False / pred_bwd_flow=True (unimatch/__init__.py:60-67) of the restatement against the real reference"""
+    g = _g(golden_dir)
+    u = np.load(os.path.join(golden_dir, "gmflow_uni.npz"), allow_pickle=False)
+    sd = state_from_fixture(g)
+    img0, img1 = make_pair(seed, *hw)
+    size = og.derive_matcher_inference_size((1, 3) + hw)
+    for name, kw in (("fwd", {}), ("bwd", {"pred_bwd_flow": True})):
+        dbg = {}
+        with torch.no_grad():
+            res = og.gmflow_forward(sd, img0, img1, size, dbg=dbg, pred_bidir_flow=False, **kw)
+        assert set(res.keys()) == {"flow"}
+        np.testing.assert_allclose(dbg["flow_match_s0"].numpy(), u["%s/%s/flow_match_s0" % (tag, name)], rtol=2e-4, atol=2e-3)
+        np.testing.assert_allclose(dbg["flow_prop_s1"].numpy(), u["%s/%s/flow_prop_s1" % (tag, name)], rtol=2e-4, atol=2e-3)
+        np.testing.assert_allclose(res["flow"].numpy(), u["%s/%s/flow" % (tag, name)], rtol=1e-3, atol=2e-2)
+
+
 def test_inference_size_rule():
     assert og.derive_matcher_inference_size((1, 3, 540, 960)) == [512, 896]           # SURVEY 2.2 C
     assert og.derive_matcher_inference_size((1, 3, 135, 240)) == [160, 256]

@@ -12,6 +12,8 @@ H, W = 1080, 1920
 g = torch.Generator(device="cuda").manual_seed(0)
 t, r, gt = (torch.rand((B, H, W, 3), device="cuda", generator=g) for _ in range(3))
 out = torch.empty_like(t)
+if len(sys.argv) > 2 and sys.argv[2] == "u8":        # uint8 frames (the u8 front door)
+    t, r, gt = ((x * 255).round().to(torch.uint8) for x in (t, r, gt))
 for _ in range(20):
     ct_hip.reinhard_persist(t, r, gt=gt, out=out)
 torch.cuda.synchronize()
