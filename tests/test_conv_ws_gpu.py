@@ -57,6 +57,24 @@ def test_conv_ws_vs_float64(hip, cfg, ws16):
         hip.set_conv_ws16(True)
 
 
+@pytest.mark.parametrize("cfg", [(2, 64, 7, 11, 40), (3, 40, 12, 6, 36), (2, 64, 72, 9, 100)])
+def test_conv_ws_writes_only_its_output(hip, cfg):
+    """Output rows leave conv_ws through a buffer descriptor over a wave's eight output planes; stores that must not happen
+    (channels past cout, columns past the image, rows of padding steps) get an out-of-range offset and are dropped by the
+    hardware (csrc/conv_ws.hip).  The output is a view inside a larger tensor of sentinels: nothing but the view may change,
+    with partial channel groups and several images (a store that was not dropped would land in the next image)."""
+    n, cin, cout, h, w = cfg
+    x, wt, b = rnd(n, cin, h, w), rnd(cout, cin, 3, 3) / (cin * 9) ** 0.5, rnd(cout)
+    wp, bp = hip.pack_conv_weight(wt.cuda(), b.cuda())
+    big = torch.full((n + 2, cout, h, w), 12345.0, device="cuda")
+    out = big[1:n + 1]
+    hip.conv2d(x.cuda(), wp, bp, cout, 3, act=1, out=out)
+    torch.cuda.synchronize()
+    assert bool((big[0] == 12345.0).all()) and bool((big[n + 1] == 12345.0).all())
+    ref = F.leaky_relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1), 0.01)
+    assert (out.double().cpu() - ref).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item())
+
+
 def test_conv_ws16_row_scales(hip):
     """Per-row power-of-two scales: rows whose magnitudes differ by 10^10 inside one image, zero rows, a scale change between
     every pair of neighbouring rows; the error stays at float32-summation level RELATIVE TO EACH OUTPUT ROW's own magnitude."""
