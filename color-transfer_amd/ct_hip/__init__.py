@@ -18,7 +18,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CT_HIP_LIB") or os.path.join(_HERE, "libct_hip.so")   # CT_HIP_LIB: tuning builds only
 
-CT_ABI_VERSION = 7            # include/ct_hip.h: CT_ABI_VERSION; lib() refuses any other library
+CT_ABI_VERSION = 8            # include/ct_hip.h: CT_ABI_VERSION; lib() refuses any other library
 CT_LAB_STATS_STRIDE = 8
 CT_RGB_STATS_STRIDE = 16
 CT_WS_LAB_STATS, CT_WS_RGB_MEANCOV, CT_WS_REINHARD, CT_WS_IDT, CT_WS_REINHARD_PSNR, CT_WS_REINHARD_PERSIST = 0, 1, 2, 3, 4, 5
@@ -690,6 +690,47 @@ def pack_conv_weight_split16(weight):
     return pieces.permute(1, 4, 7, 0, 2, 5, 3, 6).contiguous(), w_exp      # g, chunk, tap, piece, m, h, r, j
 
 
+_WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
+
+
+def pack_conv_weight_wino16(weight):
+    """3x3 Conv2d weight (32 < cin <= 64) -> ct_conv3x3_wino16_f32 operand: the Winograd F(2x2, 3x3) image U = G g G^T (float64,
+    rounded once to float32), times 2^w_exp (largest |U| in [2^11, 2^12)), as fp16 hi / lo bit patterns (int16)
+    [ceil(cout/64)][16 positions][4 cout blocks][2 cin chunks][piece][64 lanes][8]: lane l of a fragment holds cout 16 mb + l % 16,
+    cin 32 kc + 8 (l / 16) + 0..7 (the A operand of v_mfma_f32_16x16x32_f16).  Returns (image, w_exp)."""
+    cout, cin, kh, kw = weight.shape
+    assert (kh, kw) == (3, 3) and cin <= 64
+    g = (cout + 63) // 64
+    w = torch.zeros((g * 64, 64, 3, 3), dtype=torch.float64, device=weight.device)
+    w[:cout, :cin] = weight.detach().double()
+    G = torch.tensor(_WINO_G, dtype=torch.float64, device=weight.device)
+    u = torch.einsum("ij,kcjl,ml->kcim", G, w, G).float()                 # [coutp][64][4][4]
+    amax = float(u.abs().max())
+    w_exp = 0 if not (amax > 0 and amax < float("inf")) else 12 - (int(np.floor(np.log2(amax))) + 1)
+    w_exp = max(-100, min(100, w_exp))
+    us = u * (2.0 ** w_exp)
+    hi = us.to(torch.float16)
+    lo = (us - hi.float()).to(torch.float16)
+    pieces = torch.stack([hi, lo], dim=0).view(torch.int16)                # [piece][coutp][64][4][4]
+    pieces = pieces.reshape(2, g, 4, 16, 2, 4, 8, 16)                      # piece, g, mb, m, kc, kblk, e, p
+    img = pieces.permute(1, 7, 2, 4, 0, 5, 3, 6).contiguous()              # g, p, mb, kc, piece, kblk, m, e  (lane = 16 kblk + m)
+    return img.reshape(g, 16, 4, 2, 2, 64, 8), w_exp
+
+
+_wino = os.environ.get("CT_HIP_CONV_WINO", "0") not in ("0", "")
+
+
+def set_conv_wino(on):
+    """True: the 3x3 convolutions that ct_conv3x3_ws16_f32 takes run as Winograd F(2x2, 3x3) (ct_conv3x3_wino16_f32) instead.
+    Off by default (env CT_HIP_CONV_WINO=1 turns it on)."""
+    global _wino
+    _wino = bool(on)
+
+
+def conv_wino():
+    return _wino
+
+
 def _ws16_ok(x, split, kh, kw):
     return _ws16 and (kh, kw) == (3, 3) and 32 < x.shape[1] <= 64 and len(split) > 2 and split[2] is not None
 
@@ -698,7 +739,8 @@ def _split_operands(weight, bias):
     """(bf16 pieces, padded bias, fp16 image or None): what travels with a packed convolution weight as `_ct_split`"""
     cout, cin, kh, kw = weight.shape
     w16 = pack_conv_weight_split16(weight) if (kh, kw) in ((3, 3), (1, 1), (1, 5), (5, 1), (2, 2)) else None
-    return pack_conv_weight_split(weight, bias) + (w16,)
+    wq = pack_conv_weight_wino16(weight) if (kh, kw) == (3, 3) and 32 < cin <= 64 else None      # Winograd image (ct_conv3x3_wino16_f32)
+    return pack_conv_weight_split(weight, bias) + (w16, wq)
 
 
 def _split_ok(x, out, residual, kh, kw, stride, ph, pw):
@@ -775,6 +817,11 @@ def _conv_split(x, split, cout, kh, kw, act, residual, clamp, out, x2=None, x3=N
     if post_op and not f16:
         raise CtHipError("a fused post-op needs the fp16 form of the split kernel")
     if x2 is None and not res_pre and not post_op and _ws16_ok(x, split, kh, kw):
+        if _wino and len(split) > 3 and split[3] is not None:
+            wq, wq_exp = split[3]
+            check(lib().ct_conv3x3_wino16_f32(_ptr(x), _ptr(wq), int(wq_exp), _ptr(b64), _opt(residual), _ptr(out), n, cin, cout, h, w,
+                                              _nchw_bstride(x), _nchw_bstride(out), rs, int(act), int(bool(clamp)), _stream()))
+            return out
         w16, w_exp = split[2]
         check(lib().ct_conv3x3_ws16_f32(_ptr(x), _ptr(w16), int(w_exp), _ptr(b64), _opt(residual), _ptr(out), n, cin, cout, h, w,
                                         _nchw_bstride(x), _nchw_bstride(out), rs, int(act), int(bool(clamp)), _stream()))
@@ -910,6 +957,7 @@ SIGNATURES.update({
     "ct_gconv2d_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 10 + [_c_ll, _c_ll, _c_int, _c_p]),
     "ct_conv2d_split_rows_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 7 + [_c_ll, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "ct_conv3x3_ws16_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p] + [_c_int] * 5 + [_c_ll, _c_ll, _c_ll, _c_int, _c_int, _c_p]),
+    "ct_conv3x3_wino16_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p] + [_c_int] * 5 + [_c_ll, _c_ll, _c_ll, _c_int, _c_int, _c_p]),
     "ct_instance_norm_workspace_bytes": (ctypes.c_size_t, [_c_int]),
     "ct_instance_norm_f32": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_f, _c_int, _c_p, ctypes.c_size_t, _c_p]),
     "ct_eltwise_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_f, _c_p]),

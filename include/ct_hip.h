@@ -37,7 +37,7 @@ extern "C" {
  * 5: ct_reinhard_persist_*, ct_reinhard_psnr_u8, CT_WS_REINHARD_PERSIST; 6: ct_conv2d_split_f32 gained scratch / scratch_bytes;
  * 7: ct_device_status);
  * the ctypes binding refuses a library whose ct_abi_version() differs */
-#define CT_ABI_VERSION 7
+#define CT_ABI_VERSION 8
 
 /* doubles per image in a stats record written by ct_lab_stats / ct_rgb_meancov */
 #define CT_LAB_STATS_STRIDE 8  /* mean[3], std[3] (population, ddof 0), n, 0           */
@@ -322,6 +322,16 @@ int ct_conv2d_split_rows_f32(const float *in, const void *wp_split, const float 
 int ct_conv3x3_ws16_f32(const float *in, const void *wp16, int w_exp, const float *bias, const float *residual, float *out, int n,
                         int cin, int cout, int h, int w, long long in_bstride, long long out_bstride, long long res_bstride, int act,
                         int clamp, void *stream);
+
+/* The same convolution as Winograd F(2x2, 3x3) on the two fp16 pieces (csrc/conv_wino.hip): 16 instead of 36 multiplications per
+ * 2x2 output tile and channel pair, i.e. 2.25x fewer matrix instructions -- the weight-stationary kernel above runs at the chip's
+ * power limit on real data.  Same arguments, bounds and float32-grade rounding (3e-7 of the output range against float64; results
+ * are not bitwise those of ct_conv3x3_ws16_f32); every tile row of four input rows carries one power-of-two scale.
+ * wq16: fp16 bit patterns [ceil(cout/64)][16 positions][4 cout blocks][2 cin chunks][piece hi/lo][64 lanes][8] of
+ * (G g G^T) * 2^w_exp in the A-fragment order of v_mfma_f32_16x16x32_f16 (ct_hip.pack_conv_weight_wino16). */
+int ct_conv3x3_wino16_f32(const float *in, const void *wq16, int w_exp, const float *bias, const float *residual, float *out, int n,
+                          int cin, int cout, int h, int w, long long in_bstride, long long out_bstride, long long res_bstride, int act,
+                          int clamp, void *stream);
 
 /* Parallax attention, one direction (pasmnet/attention.py:39-41, utils.py:30, utils.py:123-125):
  *   P = softmax_j( sum_c q[c][h][i] k[c][h][j] / c ) ;  out_v[c][h][i] = sum_j P[i][j] v[c][h][j],

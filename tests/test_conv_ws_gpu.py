@@ -75,6 +75,41 @@ def test_conv_ws_writes_only_its_output(hip, cfg):
     assert (out.double().cpu() - ref).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item())
 
 
+WINO_CASES = [(2, 64, 64, 24, 64), (1, 64, 32, 9, 36), (1, 48, 64, 50, 100), (1, 33, 7, 5, 8), (2, 64, 130, 41, 64), (3, 64, 64, 17, 32),
+              (1, 64, 64, 2, 4), (1, 40, 64, 1, 12)]
+
+
+@pytest.mark.parametrize("cfg", WINO_CASES)
+def test_conv_wino_vs_float64(hip, cfg):
+    """ct_conv3x3_wino16_f32 (csrc/conv_wino.hip: Winograd F(2x2, 3x3) on two fp16 pieces) against the float64 convolution: odd
+    heights (half tile rows), widths that are not multiples of the 32-column strip, partial channel groups, several images and
+    segments, activation / skip / clamp; and nothing outside the output view is written."""
+    n, cin, cout, h, w = cfg
+    x, wt, b = rnd(n, cin, h, w) * 3, rnd(cout, cin, 3, 3) / (cin * 9) ** 0.5, rnd(cout)
+    x[:, :, : h // 2] *= 1e-2                       # tile rows of different magnitude
+    res = rnd(n, cout, h, w)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    wp, bp = hip.pack_conv_weight(wt.cuda(), b.cuda())
+    assert wp._ct_split[3] is not None
+    tol = 3e-6 * max(1.0, ref.abs().max().item())
+    hip.set_conv_wino(True)
+    try:
+        for act, fn in ((0, lambda t: t), (1, lambda t: F.leaky_relu(t, 0.01))):
+            big = torch.full((n + 2, cout, h, w), 12345.0, device="cuda")
+            out = hip.conv2d(x.cuda(), wp, bp, cout, 3, act=act, out=big[1:n + 1])
+            torch.cuda.synchronize()
+            assert bool((big[0] == 12345.0).all()) and bool((big[n + 1] == 12345.0).all())
+            err = (out.double().cpu() - fn(ref)).abs().max().item()
+            assert err < tol, (cfg, act, err, tol)
+        out = hip.conv2d(x.cuda(), wp, bp, cout, 3, act=1, residual=res.cuda(), clamp=True)
+        assert (out.double().cpu() - (F.leaky_relu(ref, 0.01) + res.double()).clamp(0, 1)).abs().max().item() < tol
+        a1 = hip.conv2d(x.cuda(), wp, bp, cout, 3, act=1)
+        a2 = hip.conv2d(x.cuda(), wp, bp, cout, 3, act=1)
+        assert torch.equal(a1, a2)                  # fixed summation order
+    finally:
+        hip.set_conv_wino(False)
+
+
 def test_conv_ws16_row_scales(hip):
     """Per-row power-of-two scales: rows whose magnitudes differ by 10^10 inside one image, zero rows, a scale change between
     every pair of neighbouring rows; the error stays at float32-summation level RELATIVE TO EACH OUTPUT ROW's own magnitude."""

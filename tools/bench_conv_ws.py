@@ -15,7 +15,7 @@ b = torch.randn(cout, device="cuda"); res = torch.randn(n, cout, h, w, device="c
 wp, bp = hip.pack_conv_weight(wt, b)
 out = torch.empty(n, cout, h, w, device="cuda")
 flop = 2.0 * n * h * w * cin * cout * 9
-tag = "WS=%s WS16=%s" % (os.environ.get("CT_HIP_CONV_WS", "1"), os.environ.get("CT_HIP_CONV_WS16", "1"))
+tag = "WS=%s WS16=%s WINO=%s" % (os.environ.get("CT_HIP_CONV_WS", "1"), os.environ.get("CT_HIP_CONV_WS16", "1"), os.environ.get("CT_HIP_CONV_WINO", "0"))
 for r in (None, res):
     for _ in range(3):
         hip.conv2d(x, wp, bp, cout, 3, act=1, residual=r, out=out)
