@@ -386,11 +386,13 @@ def main():
             # rates are quoted in algorithmic (float32) FLOPs, and x3 (MFMA flops issued) against the dense 16-bit peak.
             ws16 = ct_hip.conv_ws16() and ct_hip.conv_mode() == "split"
             extra["cnn_conv_arithmetic"] = (
-                "float32 operands, float32 accumulate; convolutions (weight-stationary conv_ws for the ResB convs, tile kernel "
-                "conv_split elsewhere), attention (attention16) and the FFN linears (linear_ws16): 2 fp16 pieces with power-of-two "
+                "float32 operands, float32 accumulate; convolutions (Winograd F(2x2,3x3) conv_wino for the ResB convs -- conv_ws, the "
+                "direct weight-stationary form, with CT_HIP_CONV_WINO=0 --, tile kernel conv_split elsewhere), attention (attention16) and the FFN linears (linear_ws16): 2 fp16 pieces with power-of-two "
                 "scales, 3 fp16 MFMAs per product; the 128 -> 128 token projections: 3 bf16 pieces, 6 MFMAs per product"
                 if ws16 else "f32 as 3 bf16 pieces, 6 bf16 MFMAs per product, f32 accumulate (%s mode)" % ct_hip.conv_mode())
-            mfma_per_flop = 3.0 if ws16 else 6.0       # MFMA flops issued per algorithmic (float32) flop in the dominant convs
+            # MFMA flops issued per algorithmic (float32) flop in the dominant convs: 3 products of fp16 pieces (6 of bf16 pieces), and
+            # with the Winograd form (default since round 5, csrc/conv_wino.hip) 16 instead of 36 multiplications per 2x2 tile: 3 / 2.25
+            mfma_per_flop = (3.0 / 2.25 if ct_hip.conv_wino() else 3.0) if ws16 else 6.0
             from methods.dcmcs3di import DCMCS3DI
             torch.manual_seed(0)
             net = DCMCS3DI().to(device).eval()
@@ -413,7 +415,7 @@ def main():
             # the committed counter profile of the same forward (SQ_VALU_MFMA_BUSY_CYCLES over all kernels of the run, time
             # weighted, profiles/r02_dcmcs3di_1080p_mfma_pmc.json); achieved = issued bf16-MFMA-equivalent work, live.
             busy = read_stamped(os.path.join(ROOT, "profiles", "r05_dcmcs3di_1080p_mfma_pmc.json")) or {}      # {} unless measured on this tree's sources
-            kdom = [v for k, v in busy.items() if "conv_ws_kernel" in k]
+            kdom = [v for k, v in busy.items() if "conv_wino_kernel<1>" in k] or [v for k, v in busy.items() if "conv_wino_kernel" in k]
             roof_cnn = {"bound": "mfma", "workload": "dcmcs3di forward, random init, 1 pair of 1920x1080, float32 I/O",
                         "dtype": "16-bit MFMA pipe (float32 operands as 2 fp16 pieces / 3 MFMAs per product in the convolutions and the "
                                  "attention), f32 accumulate",
@@ -426,11 +428,13 @@ def main():
                         "forward": t1080,
                         "frac_definition": "MFMA-busy: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), time-weighted over every "
                                            "kernel of the forward",
-                        "dominant_kernel": "conv_ws_kernel<1, true>",
+                        "dominant_kernel": "conv_wino_kernel<1>",
                         "dominant_kernel_mfma_busy": kdom[0].get("mfma_busy_frac") if kdom else None,
                         "pairs_per_s": dc2, "algorithmic_f32_tflops": flop2 * dc2 / 1e12,
-                        "note": "achieved = MFMA flops issued (3 per algorithmic flop in the fp16 two-piece convs); on real data the 16-bit "
-                                "matrix pipe of this chip is power limited near 1.1-1.3 PFLOP/s (DESIGN.md 4.4)"}
+                        "note": "achieved = MFMA flops issued, priced at the dominant convolutions' rate: 3 products of fp16 pieces per float32 "
+                                "product and 2.25x fewer multiplications as Winograd F(2x2,3x3) = 1.33 per algorithmic flop (the attention and "
+                                "the 1x1 / first / last convolutions issue 3); on real data the 16-bit matrix pipe of this chip is power "
+                                "limited near 1.1-1.3 PFLOP/s (DESIGN.md 4.4)"}
             del net, l1080, r1080
             # configs[3]: GMFlow matcher as DMSCT calls it (bidirectional + occlusion), random init, 540x960 -> 512x896
             from unimatch import GMFlow

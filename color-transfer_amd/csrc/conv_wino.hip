@@ -169,6 +169,11 @@ __global__ __launch_bounds__(kWnThreads, 1) void conv_wino_kernel(ConvArgs a, in
             }
         }
         __syncthreads();
+        // rows travel one step ahead of their staging: requested in the matrix phase of step s - 1 (here: rows 4, 5), staged in the
+        // matrix phase of step s -- vector and LDS work in the shadow of the MFMAs -- and first read by the transform of step s + 1
+        float4 na0, na1, nb0, nb1;
+        fetch(4, na0, na1);
+        fetch(5, nb0, nb1);
 
         // skip rows (D role): columns x0 + 2 dn, couts dc, dc + 32; clamped addresses (without a skip tensor the output is read and ignored)
         const int ox = x0 + 2 * dn;
@@ -192,6 +197,7 @@ __global__ __launch_bounds__(kWnThreads, 1) void conv_wino_kernel(ConvArgs a, in
             const int oy = y0 + 2 * s;
             // the tile row's scale: 2^ex * max |x| in [2^9, 2^10): |V| <= 4 max |x| stays below 2^12 like conv_ws's staged rows
             const float mx = fmaxf(__uint_as_float(rowmax[SB / 2]), __uint_as_float(rowmax[((SB + 2) % kWnRing) / 2]));
+            if (tid == 0) rowmax[((SB + 4) % kWnRing) / 2] = 0u;    // the pair staged in this step's matrix phase (a barrier from here); last read a step ago
             const int fld = (int)(__float_as_uint(mx) >> 23);
             int ex = (fld == 0 || fld == 255) ? 0 : 136 - fld;
             ex = __builtin_amdgcn_readfirstlane(min(max(ex, -100), 100));
@@ -234,11 +240,7 @@ __global__ __launch_bounds__(kWnThreads, 1) void conv_wino_kernel(ConvArgs a, in
                 }
             }
             WN_STAMP(1);
-            // requests, issued AFTER the transform (its 80 live values and the 128 weight registers fill the file): the next step's
-            // two new rows (rr = 2s + 4, 2s + 5), staged at the end of this step, and the skip rows of this step's outputs
-            float4 na0, na1, nb0, nb1;
-            fetch(2 * s + 4, na0, na1);
-            fetch(2 * s + 5, nb0, nb1);
+            // the skip rows of this step's outputs, requested after the transform (its live values and the 128 weight registers fill the file)
             float2 rq[2][2];
             {
                 const unsigned int yy0 = (unsigned int)(min(oy, a.H - 1) * a.W), yy1 = (unsigned int)(min(oy + 1, a.H - 1) * a.W);
@@ -248,35 +250,55 @@ __global__ __launch_bounds__(kWnThreads, 1) void conv_wino_kernel(ConvArgs a, in
             __syncthreads();
             WN_STAMP(2);
             // ---------------- C: fragments of the own positions, MFMAs, M image (in place of the fragments) ----------------
-            if (tid == 0) rowmax[((SB + 4) % kWnRing) / 2] = 0u;    // the pair of rows staged below; last read at the top of step s - 1
             {
+                // The matrix phase: six groups of eight independent MFMAs (one per accumulator); between the groups -- fenced, so that
+                // the order survives the scheduler -- the vector work that depends on nothing here: rows 2s + 4, 2s + 5 (requested a
+                // step ago) -> ring, their maximum, then the requests for rows 2s + 6, 2s + 7 into the same registers.  A group
+                // issues in 32 cycles and keeps the matrix pipe busy for 128: the filler runs in its shadow.
                 f32x4w acc[2][4];
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
                     for (int mb = 0; mb < 4; ++mb) acc[q][mb] = f32x4w{0.f, 0.f, 0.f, 0.f};
-                WN_STAMP(3);
+                uint4 bq0[2][2], bq1[2][2];
 #pragma unroll
-                for (int kc = 0; kc < 2; ++kc) {
-                    // the fragments of one cin chunk at a time (16 registers; all eight would not fit beside 128 of weights)
-                    uint4 bq[2][2];
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) bq0[q][pc] = reinterpret_cast<const uint4 *>(vimg)[(((2 * wave + q) * 2 + 0) * 2 + pc) * 64 + lane];
+                WN_STAMP(3);
+                auto group = [&](int kc, int pr, const uint4 (&bq)[2][2]) {      // small terms first: lo x hi, hi x lo, hi x hi
+                    const int pw = pr == 0 ? 1 : 0, pv = pr == 1 ? 1 : 0;
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
 #pragma unroll
-                        for (int pc = 0; pc < 2; ++pc)
-                            bq[q][pc] = reinterpret_cast<const uint4 *>(vimg)[(((2 * wave + q) * 2 + kc) * 2 + pc) * 64 + lane];
-#pragma unroll
-                    for (int pr = 0; pr < 3; ++pr) {      // small terms first: lo x hi, hi x lo, hi x hi
-                        const int pw = pr == 0 ? 1 : 0, pv = pr == 1 ? 1 : 0;
-#pragma unroll
-                        for (int q = 0; q < 2; ++q)
-#pragma unroll
-                            for (int mb = 0; mb < 4; ++mb)
-                                acc[q][mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, wreg[q][mb][kc][pw]),
-                                                                                    __builtin_bit_cast(h16x8, bq[q][pv]), acc[q][mb], 0, 0, 0);
-                    }
+                        for (int mb = 0; mb < 4; ++mb)
+                            acc[q][mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, wreg[q][mb][kc][pw]),
+                                                                                __builtin_bit_cast(h16x8, bq[q][pv]), acc[q][mb], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                }
+                };
+                float m = 0.f;
+                __builtin_amdgcn_sched_barrier(0);
+                group(0, 0, bq0);
+                stage(2 * s + 4, (SB + 4) % kWnRing, na0, na1, m);
+                __builtin_amdgcn_sched_barrier(0);
+                group(0, 1, bq0);
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) bq1[q][pc] = reinterpret_cast<const uint4 *>(vimg)[(((2 * wave + q) * 2 + 1) * 2 + pc) * 64 + lane];
+                stage(2 * s + 5, (SB + 5) % kWnRing, nb0, nb1, m);
+                __builtin_amdgcn_sched_barrier(0);
+                group(0, 2, bq0);
+                m = wn_wave_max(m);
+                if (lane == 0) atomicMax(rowmax + ((SB + 4) % kWnRing) / 2, __float_as_uint(m));
+                __builtin_amdgcn_sched_barrier(0);
+                group(1, 0, bq1);
+                fetch(2 * s + 6, na0, na1);
+                __builtin_amdgcn_sched_barrier(0);
+                group(1, 1, bq1);
+                fetch(2 * s + 7, nb0, nb1);
+                __builtin_amdgcn_sched_barrier(0);
+                group(1, 2, bq1);
                 const float unscale = __uint_as_float((unsigned int)(127 + min(max(-ex - a.w_exp, -126), 127)) << 23);
                 // lane holds M[cout 16 mb + 4 (lane / 16) + i][tile lane % 16]
                 float *mw = mimg + (2 * wave) * 1024 + (lane >> 4) * 16 + (lane & 15);
@@ -324,15 +346,7 @@ __global__ __launch_bounds__(kWnThreads, 1) void conv_wino_kernel(ConvArgs a, in
                 }
             }
             WN_STAMP(6);
-            // ---------------- the next step's rows -> ring: their slots were last read in T of step s - 1 ----------------
-            {
-                float m = 0.f;
-                stage(2 * s + 4, (SB + 4) % kWnRing, na0, na1, m);
-                stage(2 * s + 5, (SB + 5) % kWnRing, nb0, nb1, m);
-                m = wn_wave_max(m);
-                if (lane == 0) atomicMax(rowmax + ((SB + 4) % kWnRing) / 2, __float_as_uint(m));
-            }
-            __syncthreads();                              // M image consumed, ring rows and their maxima published
+            __syncthreads();                              // M image consumed (the next transform overwrites it)
             WN_STAMP(7);
         };
 #pragma unroll 1

@@ -717,12 +717,12 @@ def pack_conv_weight_wino16(weight):
     return img.reshape(g, 16, 4, 2, 2, 64, 8), w_exp
 
 
-_wino = os.environ.get("CT_HIP_CONV_WINO", "0") not in ("0", "")
+_wino = os.environ.get("CT_HIP_CONV_WINO", "1") not in ("0", "")
 
 
 def set_conv_wino(on):
-    """True: the 3x3 convolutions that ct_conv3x3_ws16_f32 takes run as Winograd F(2x2, 3x3) (ct_conv3x3_wino16_f32) instead.
-    Off by default (env CT_HIP_CONV_WINO=1 turns it on)."""
+    """True (default; env CT_HIP_CONV_WINO=0 turns it off): the 3x3 convolutions that ct_conv3x3_ws16_f32 would take run as
+    Winograd F(2x2, 3x3) (ct_conv3x3_wino16_f32: 2.25x fewer matrix instructions, float32-grade); False: the direct kernel."""
     global _wino
     _wino = bool(on)
 

@@ -45,10 +45,15 @@ def golden_dir():
     return GOLDEN
 
 
-@pytest.fixture(params=["split", "exact"])
+@pytest.fixture(params=["split", "split-ws", "exact"])
 def conv_mode(request):
-    """Both arithmetic paths of the stride-1 convolutions: split-bf16 MFMA (default) and exact-f32 MFMA."""
+    """The arithmetic paths of the stride-1 convolutions: split MFMA (default; the 3x3 convolutions with 32 < cin <= 64 as Winograd
+    F(2x2,3x3), csrc/conv_wino.hip), the same with those convolutions on the weight-stationary direct kernel (csrc/conv_ws.hip;
+    "split-ws", yields "split"), and exact-f32 MFMA."""
     import ct_hip
-    ct_hip.set_conv_mode(request.param)
-    yield request.param
+    mode = "exact" if request.param == "exact" else "split"
+    ct_hip.set_conv_mode(mode)
+    ct_hip.set_conv_wino(request.param == "split")
+    yield mode
     ct_hip.set_conv_mode("split")
+    ct_hip.set_conv_wino(True)

@@ -22,6 +22,15 @@ def hip():
     return ct_hip
 
 
+@pytest.fixture(autouse=True)
+def direct_kernel(hip):
+    """This module tests the direct kernels (conv_ws, conv_split) by name: the Winograd form that takes conv_ws's convolutions by
+    default is switched off here and on again inside its own tests (test_conv_wino_*)."""
+    hip.set_conv_wino(False)
+    yield
+    hip.set_conv_wino(True)
+
+
 CASES = [(2, 64, 64, 24, 64), (1, 64, 32, 9, 36), (1, 48, 64, 50, 100), (1, 33, 7, 5, 8), (1, 64, 130, 40, 64), (3, 64, 64, 17, 32)]
 
 
@@ -106,6 +115,33 @@ def test_conv_wino_vs_float64(hip, cfg):
         a1 = hip.conv2d(x.cuda(), wp, bp, cout, 3, act=1)
         a2 = hip.conv2d(x.cuda(), wp, bp, cout, 3, act=1)
         assert torch.equal(a1, a2)                  # fixed summation order
+    finally:
+        hip.set_conv_wino(False)
+
+
+def test_conv_wino_graph_replay_and_second_stream(hip):
+    """the Winograd kernel allocates nothing and keeps no host state: captured in a graph and replayed, and launched on a second
+    stream, it gives the eager result bit for bit"""
+    n, cin, cout, h, w = 2, 64, 64, 30, 64
+    x, wt, b = rnd(n, cin, h, w).cuda(), (rnd(cout, cin, 3, 3) / 24).cuda(), rnd(cout).cuda()
+    wp, bp = hip.pack_conv_weight(wt, b)
+    hip.set_conv_wino(True)
+    try:
+        want = hip.conv2d(x, wp, bp, cout, 3, act=1)
+        out = torch.empty_like(want)
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            hip.conv2d(x, wp, bp, cout, 3, act=1, out=out)
+        torch.cuda.current_stream().wait_stream(s)
+        assert torch.equal(out, want)
+        out.zero_()
+        with torch.cuda.graph(g):
+            hip.conv2d(x, wp, bp, cout, 3, act=1, out=out)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
     finally:
         hip.set_conv_wino(False)
 
