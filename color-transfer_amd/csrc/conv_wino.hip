@@ -28,7 +28,8 @@ namespace ct {
 constexpr int kWnTiles = 16;           // 2x2 tiles per step = MFMA N: 32 output columns x 2 output rows
 constexpr int kWnTW = 2 * kWnTiles;    // output columns of a strip
 constexpr int kWnGroups = 10;          // staged input columns x0-4 .. x0+35 as aligned groups of four
-constexpr int kWnRowStride = 44;       // floats per channel row of the ring; index = column - (x0 - 4) + 1 (tile t starts at 2t + 4: 8-byte aligned)
+constexpr int kWnRowStride = 44;       // floats per channel row of the ring; index = column - (x0 - 4) + 1: tile t reads 2t + 4 .. 2t + 7 as two aligned
+                                       // 8-byte words (16-byte aligned staging with 4-byte reads instead: 925 -> 1115 us)
 constexpr int kWnRing = 6;             // input rows resident: four in use, two being filled
 constexpr int kWnMStride = 17;         // floats per (position, cout) row of the M image (16 tiles + 1)
 constexpr int kWnThreads = 512;
@@ -63,6 +64,9 @@ __global__ __launch_bounds__(kWnThreads, 1) void conv_wino_kernel(ConvArgs a, in
     unsigned int *vimg = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(wn_smem) + kWnRingBytes);   // V image (32-bit words)
     // M image: position p's 4 KB are the SAME bytes as its V fragments -- only the wave that owns p reads the one and writes the
     // other, so no barrier separates them.  float index in a position: ((mb 4 + i) 4 + k) 16 + tile for cout 16 mb + 4 k + i
+    // (tried and not kept, same-box A/B: swizzling k with i against the bank conflicts of the output transform's reads: no change;
+    // the matrix phase in two cout halves with the first half's output transform in the shadow of the second: one more barrier
+    // eats what the overlap wins, 1.215 -> 1.197 x conv_ws)
     float *mimg = reinterpret_cast<float *>(vimg);
     unsigned int *rowmax = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(wn_smem) + kWnLds - 64);   // [slot]: bits of max |x| of the row
     const int tid = threadIdx.x, lane = tid & 63;
@@ -225,18 +229,24 @@ __global__ __launch_bounds__(kWnThreads, 1) void conv_wino_kernel(ConvArgs a, in
                         v[e][i][0] = w[i][0] - w[i][2]; v[e][i][1] = w[i][1] + w[i][2]; v[e][i][2] = w[i][2] - w[i][1]; v[e][i][3] = w[i][1] - w[i][3];
                     }
                 }
+                // hi = fp16(v 2^ex), lo = fp16(v 2^ex - hi): the scale rides in the converting fma (v_fma_mixlo / mixhi_f16 write one
+                // half of the word each): four instructions per channel pair and position instead of six.  Issued in four sweeps over
+                // the positions: a half-word write followed at once by its other half or by its reader costs wait states
+                unsigned int hw[16], lw[16];
+#pragma unroll
+                for (int p = 0; p < 16; ++p) asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hw[p]) : "v"(v[0][p >> 2][p & 3]), "v"(scale));
+#pragma unroll
+                for (int p = 0; p < 16; ++p) asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hw[p]) : "v"(v[1][p >> 2][p & 3]), "v"(scale));
+#pragma unroll
+                for (int p = 0; p < 16; ++p)
+                    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lw[p]) : "v"(v[0][p >> 2][p & 3]), "v"(scale), "v"(hw[p]));
+#pragma unroll
+                for (int p = 0; p < 16; ++p)
+                    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lw[p]) : "v"(v[1][p >> 2][p & 3]), "v"(scale), "v"(hw[p]));
 #pragma unroll
                 for (int p = 0; p < 16; ++p) {
-                    // hi = fp16(v 2^ex), lo = fp16(v 2^ex - hi): the scale rides in the converting fma (v_fma_mixlo / mixhi_f16 write one
-                    // half of the word each), four instructions per channel pair and position instead of six
-                    const float va = v[0][p >> 2][p & 3], vc = v[1][p >> 2][p & 3];
-                    unsigned int h, l;
-                    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(va), "v"(scale));
-                    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(vc), "v"(scale));
-                    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(va), "v"(scale), "v"(h));
-                    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(vc), "v"(scale), "v"(h));
-                    vb[p * (2 * 2 * 64 * 4)] = h;                        // [p][kc][piece][lane][4 words]
-                    vb[p * (2 * 2 * 64 * 4) + 64 * 4] = l;
+                    vb[p * (2 * 2 * 64 * 4)] = hw[p];                    // [p][kc][piece][lane][4 words]
+                    vb[p * (2 * 2 * 64 * 4) + 64 * 4] = lw[p];
                 }
             }
             WN_STAMP(1);
