@@ -430,6 +430,10 @@ def main():
                                            "kernel of the forward",
                         "dominant_kernel": "conv_wino_kernel<1>",
                         "dominant_kernel_mfma_busy": kdom[0].get("mfma_busy_frac") if kdom else None,
+                        "frac_note": "MFMA-busy is not comparable with rounds 2-4: as Winograd F(2x2,3x3) the ResB convolutions (73 % of the "
+                                     "forward) issue 2.25x fewer matrix instructions per output than the direct kernel did (busy 0.40 at "
+                                     "1.0 ms per 2-view conv then, 0.18 at 0.83 ms now, at 2.24 instead of 1.92 GHz: the direct form ran "
+                                     "into the chip's power limit).  pairs_per_s is the figure to compare",
                         "pairs_per_s": dc2, "algorithmic_f32_tflops": flop2 * dc2 / 1e12,
                         "note": "achieved = MFMA flops issued, priced at the dominant convolutions' rate: 3 products of fp16 pieces per float32 "
                                 "product and 2.25x fewer multiplications as Winograd F(2x2,3x3) = 1.33 per algorithmic flop (the attention and "
