@@ -817,7 +817,7 @@ def _conv_split(x, split, cout, kh, kw, act, residual, clamp, out, x2=None, x3=N
     if post_op and not f16:
         raise CtHipError("a fused post-op needs the fp16 form of the split kernel")
     if x2 is None and not res_pre and not post_op and _ws16_ok(x, split, kh, kw):
-        if _wino and len(split) > 3 and split[3] is not None:
+        if _wino and len(split) > 3 and split[3] is not None and h * w * 256 < (1 << 32):      # 32-bit byte offsets over 64 output planes; larger: the direct kernel
             wq, wq_exp = split[3]
             check(lib().ct_conv3x3_wino16_f32(_ptr(x), _ptr(wq), int(wq_exp), _ptr(b64), _opt(residual), _ptr(out), n, cin, cout, h, w,
                                               _nchw_bstride(x), _nchw_bstride(out), rs, int(act), int(bool(clamp)), _stream()))

@@ -2,6 +2,7 @@
 its bf16 three-piece form, against float64 torch convolutions: every geometry branch (partial strips, row segments that are
 not multiples of three, fewer than four input chunks, odd channel counts, several output groups), every epilogue, and the
 per-row power-of-two scaling (rows of very different magnitude, zero rows, scale changes between neighbouring rows)."""
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -115,6 +116,36 @@ def test_conv_wino_vs_float64(hip, cfg):
         a1 = hip.conv2d(x.cuda(), wp, bp, cout, 3, act=1)
         a2 = hip.conv2d(x.cuda(), wp, bp, cout, 3, act=1)
         assert torch.equal(a1, a2)                  # fixed summation order
+    finally:
+        hip.set_conv_wino(False)
+
+
+def test_conv_wino_random_shapes(hip):
+    """30 seeded random geometries (heights 1..70, widths 4..132 in steps of 4, 33..64 input channels, 1..130 output channels,
+    1..3 images, every activation the entry takes, with and without skip / clamp) against the float64 convolution"""
+    rs = np.random.RandomState(7)
+    hip.set_conv_wino(True)
+    try:
+        for it in range(30):
+            n, cin, cout = int(rs.randint(1, 4)), int(rs.randint(33, 65)), int(rs.randint(1, 131))
+            h, w = int(rs.randint(1, 71)), 4 * int(rs.randint(1, 34))
+            act, use_res, clamp = int(rs.randint(0, 4)), bool(rs.randint(0, 2)), bool(rs.randint(0, 2))
+            x, wt, b = rnd(n, cin, h, w) * float(10.0 ** rs.uniform(-3, 2)), rnd(cout, cin, 3, 3) / (cin * 9) ** 0.5, rnd(cout)
+            res = rnd(n, cout, h, w) if use_res else None
+            ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+            want = (ref, F.leaky_relu(ref, 0.01), torch.relu(ref), torch.sigmoid(ref))[act]
+            if act < 2:                                  # conv2d: LeakyReLU or none, skip tensor, clamp
+                if use_res:
+                    want = want + res.double()
+                if clamp:
+                    want = want.clamp(0, 1)
+                wp, bp = hip.pack_conv_weight(wt.cuda(), b.cuda())
+                out = hip.conv2d(x.cuda(), wp, bp, cout, 3, act=act, residual=res.cuda() if use_res else None, clamp=clamp)
+            else:                                        # gconv2d: the generic activations
+                wpg, bpg = hip.pack_gconv_weight(wt.cuda(), b.cuda())
+                out = hip.gconv2d(x.cuda(), wpg, bpg, cout, 3, 1, 1, act=act)
+            err = (out.double().cpu() - want).abs().max().item()
+            assert err < 3e-6 * max(1.0, ref.abs().max().item()), (it, (n, cin, cout, h, w, act, use_res, clamp), err)
     finally:
         hip.set_conv_wino(False)
 
