@@ -196,6 +196,36 @@ def test_fp16_piece_packings_layout_and_value():
         assert v[(cout + 63) // 64 - 1, :, :, :, 1, :, (cout % 32 or 32):].abs().sum() == 0 or cout % 64 == 0 or cout % 64 > 32
 
 
+def test_winograd_weight_packing_layout_and_value():
+    """ct_hip.pack_conv_weight_wino16 (the operand of ct_conv3x3_wino16_f32, include/ct_hip.h): hi + lo == (G g G^T) * 2^w_exp to
+    2^-21 relative with G g G^T taken in float64, the largest element in [2^11, 2^12), every (group, position, cout block, cin
+    chunk, piece, lane, element) where the header says it is, zero padding of absent channels"""
+    import ct_hip
+    g = torch.Generator().manual_seed(5)
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    for cout, cin in ((64, 64), (70, 40), (5, 33)):
+        w = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+        img, w_exp = ct_hip.pack_conv_weight_wino16(w)
+        groups = (cout + 63) // 64
+        assert img.shape == (groups, 16, 4, 2, 2, 64, 8) and img.dtype == torch.int16
+        u = torch.einsum("ij,kcjl,ml->kcim", G, w.double(), G)             # [cout][cin][4][4]
+        amax = (u.float().abs().max() * 2.0 ** w_exp).item()
+        assert 2048 <= amax < 4096
+        v = img.view(torch.float16).double()
+        for (co, ci, pi, pj) in [(0, 0, 0, 0), (cout - 1, cin - 1, 3, 3), (cout // 2, cin // 3, 1, 2), (cout - 1, 0, 2, 1)]:
+            want = float(u[co, ci, pi, pj].float()) * 2.0 ** w_exp        # the transform is rounded once to float32
+            lane = 16 * ((ci % 32) // 8) + (co % 64) % 16
+            idx = (co // 64, 4 * pi + pj, (co % 64) // 16, ci // 32, slice(None), lane, ci % 8)
+            got = v[idx].sum().item()
+            assert abs(got - want) <= 2.0 ** -21 * abs(want) + 2.0 ** -24, (co, ci, pi, pj, got, want)
+        if cin < 64:                                                        # channels cin .. 63 are zero
+            lanes = [16 * ((c % 32) // 8) + m for c in range(cin, 64) for m in range(16) if c % 8 == 0]
+            assert v[:, :, :, 1, :, :, :][..., [16 * 3 + m for m in range(16)], 7].abs().sum() == 0      # cin 63: chunk 1, k-block 3, element 7
+        if cout % 64:                                                       # couts past cout are zero
+            co = cout % 64
+            assert v[groups - 1, :, co // 16, :, :, [16 * kb + co % 16 for kb in range(4)], :].abs().sum() == 0
+
+
 def test_sharding_arithmetic():
     from utils import sharding as sh
     assert sh.frames_of_rank(10, 1, 4) == [1, 5, 9]
