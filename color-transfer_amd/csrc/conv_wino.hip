@@ -57,7 +57,9 @@ __device__ __forceinline__ float wn_wave_max(float v) {        // v >= 0; every 
 }
 
 // ACTK: compile-time activation (0 none, 1 LeakyReLU(0.01), 2 ReLU, 3 = switch over a.act at run time), as in conv_ws.hip
-template <int ACTK>
+// HAS_RES: a skip tensor is added after the activation; without one no skip row is requested at all (round 6: the no-skip launches
+// used to read their own not-yet-written output as a dummy row -- 1.06 GB per 2-view 1080p launch for nothing)
+template <int ACTK, bool HAS_RES>
 __global__ __launch_bounds__(kWnThreads, 1) void conv_wino_kernel(ConvArgs a, int n_strips, int seg, int n_seg, int n_items) {
     extern __shared__ uint4 wn_smem[];
     float *ring = reinterpret_cast<float *>(wn_smem);                                         // [slot][channel][kWnRowStride]
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(kWnThreads, 1) void conv_wino_kernel(ConvArgs a, in
         const int rows = min(seg, a.H - y0);
         const float *in = a.in + (size_t)nimg * a.in_bstride;
         float *out = a.out + (size_t)nimg * a.out_bstride + (size_t)grp * 64 * plane;
-        const float *res = a.residual ? a.residual + (size_t)nimg * a.res_bstride + (size_t)grp * 64 * plane : nullptr;
+        const float *res = HAS_RES ? a.residual + (size_t)nimg * a.res_bstride + (size_t)grp * 64 * plane : nullptr;
         const int cout_g = a.cout - grp * 64;
         const float bias0 = a.bias[grp * 64 + dc], bias1 = a.bias[grp * 64 + dc + 32];
         // stores through a buffer descriptor over this group's output planes: out-of-range offsets are dropped (conv_ws.hip)
@@ -179,9 +181,9 @@ __global__ __launch_bounds__(kWnThreads, 1) void conv_wino_kernel(ConvArgs a, in
         fetch(4, na0, na1);
         fetch(5, nb0, nb1);
 
-        // skip rows (D role): columns x0 + 2 dn, couts dc, dc + 32; clamped addresses (without a skip tensor the output is read and ignored)
+        // skip rows (D role): columns x0 + 2 dn, couts dc, dc + 32; clamped addresses
         const int ox = x0 + 2 * dn;
-        const float *rb = res ? res : out;
+        const float *rb = res;
         const unsigned int rb0 = (unsigned int)min(dc, cout_g - 1) * uplane + (unsigned int)min(ox, a.W - 2);
         const unsigned int rb1 = (unsigned int)min(dc + 32, cout_g - 1) * uplane + (unsigned int)min(ox, a.W - 2);
         const int dco[2] = {dc, dc + 32};
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(kWnThreads, 1) void conv_wino_kernel(ConvArgs a, in
             WN_STAMP(1);
             // the skip rows of this step's outputs, requested after the transform (its live values and the 128 weight registers fill the file)
             float2 rq[2][2];
-            {
+            if constexpr (HAS_RES) {
                 const unsigned int yy0 = (unsigned int)(min(oy, a.H - 1) * a.W), yy1 = (unsigned int)(min(oy + 1, a.H - 1) * a.W);
                 rq[0][0] = *reinterpret_cast<const float2 *>(rb + (rb0 + yy0)); rq[0][1] = *reinterpret_cast<const float2 *>(rb + (rb0 + yy1));
                 rq[1][0] = *reinterpret_cast<const float2 *>(rb + (rb1 + yy0)); rq[1][1] = *reinterpret_cast<const float2 *>(rb + (rb1 + yy1));
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(kWnThreads, 1) void conv_wino_kernel(ConvArgs a, in
                     else if constexpr (ACTK == 2) y[i] = fmaxf(y[i], 0.f);
                     else if constexpr (ACTK == 3) y[i] = split_act<true>(y[i], a.act);
                 }
-                if (res != nullptr) { y[0] += rq[j][0].x; y[1] += rq[j][0].y; y[2] += rq[j][1].x; y[3] += rq[j][1].y; }
+                if constexpr (HAS_RES) { y[0] += rq[j][0].x; y[1] += rq[j][0].y; y[2] += rq[j][1].x; y[3] += rq[j][1].y; }
                 if (a.clamp) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) y[i] = fminf(fmaxf(y[i], 0.f), 1.f);
@@ -378,6 +380,10 @@ __global__ __launch_bounds__(kWnThreads, 1) void conv_wino_kernel(ConvArgs a, in
 static unsigned long long *g_wn_prof = nullptr;
 #endif
 
+// which Winograd kernel ct_conv3x3_wino16_f32 launches: 0 = conv_wino4.hip (four waves of 512 registers, pipelined; round 6, the
+// default), 1 = the eight-wave kernel of this file (round 5).  Process-wide, atomic; env CT_HIP_WINO_FORM presets it.
+static std::atomic<int> g_wino_form{[] { const char *e = getenv("CT_HIP_WINO_FORM"); return (e && e[0] == '1') ? 1 : 0; }()};
+
 // 1 = not this kernel's geometry
 int conv_wino(const ConvArgs &a, int N, hipStream_t s) {
     if (a.in2 != nullptr || a.cin <= 32 || a.cin > 64 || !a.f16 || (a.W & 3)) return 1;
@@ -398,9 +404,10 @@ int conv_wino(const ConvArgs &a, int N, hipStream_t s) {
     const long long n_items = imgs * n_seg * n_strips;
     if (n_items > 0x7fffffffLL) return CT_E_BADARG;
     typedef void (*kern_t)(ConvArgs, int, int, int, int);
-    static const kern_t kerns[4] = {conv_wino_kernel<0>, conv_wino_kernel<1>, conv_wino_kernel<2>, conv_wino_kernel<3>};
-    const int actk = (a.act >= 0 && a.act <= 2) ? a.act : 3;
-    static DynLdsAttr attr[4];
+    static const kern_t kerns[8] = {conv_wino_kernel<0, false>, conv_wino_kernel<1, false>, conv_wino_kernel<2, false>, conv_wino_kernel<3, false>,
+                                    conv_wino_kernel<0, true>,  conv_wino_kernel<1, true>,  conv_wino_kernel<2, true>,  conv_wino_kernel<3, true>};
+    const int actk = ((a.act >= 0 && a.act <= 2) ? a.act : 3) + (a.residual ? 4 : 0);
+    static DynLdsAttr attr[8];
     if (attr[actk].ensure(reinterpret_cast<const void *>(kerns[actk]), kWnLds) != hipSuccess) return CT_E_BADARG;
     ConvArgs b = a;
     b.n_images = N;
@@ -435,8 +442,16 @@ int ct_conv3x3_wino16_f32(const float *in, const void *wq16, int w_exp, const fl
     a.in_bstride = in_bstride; a.out_bstride = out_bstride; a.res_bstride = res_bstride;
     a.act = act; a.clamp = clamp; a.groups = (cout + 63) / 64; a.prof = nullptr;
     a.f16 = 1; a.w_exp = w_exp;
-    const int rc = ct::conv_wino(a, n, (hipStream_t)stream);
+    int rc = 1;
+    if (ct::g_wino_form.load(std::memory_order_relaxed) == 0) rc = ct::conv_wino4(a, n, (hipStream_t)stream);   // 1: geometry beyond its 30-bit offsets
+    if (rc == 1) rc = ct::conv_wino(a, n, (hipStream_t)stream);
     return rc == 1 ? CT_E_BADARG : rc;
+}
+
+int ct_set_conv_wino_form(int form) {
+    if (form != 0 && form != 1) return CT_E_BADARG;
+    ct::g_wino_form.store(form, std::memory_order_relaxed);
+    return CT_OK;
 }
 
 #ifdef CT_WN_PROFILE

@@ -254,9 +254,9 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs a, int n_strip
         };
 
         auto fetch_skip = [&](int r, float4 &rv) {             // ResB skip of output row y0 + r: branch-free like the row fetch
-            const int yr = min(max(y0 + r, 0), a.H - 1);        // (without a skip tensor the output row is read and ignored)
-            rv = *reinterpret_cast<const float4 *>((res ? res : out) + (unsigned int)min(e_co, cout_g - 1) * uplane +
-                                                   (unsigned int)(yr * a.W + min(x0 + 4 * e_g, a.W - 4)));
+            const int yr = min(max(y0 + r, 0), a.H - 1);        // (without a skip tensor: one cached line of the bias, ignored -- the
+            const unsigned int so = (unsigned int)min(e_co, cout_g - 1) * uplane + (unsigned int)(yr * a.W + min(x0 + 4 * e_g, a.W - 4));
+            rv = *reinterpret_cast<const float4 *>(res ? res + so : a.bias);   // request count per step stays what the exact waits assume; round 5 read the output row here: 1.06 GB per launch)
         };
         // prologue: input rows y0-1, y0, y0+1 -> slots 0, 1, 2 (the barrier publishes them to the chunk's other wave); rows
         // y0+2 and y0+3 are requested now and staged at the end of steps 0 and 1

@@ -59,4 +59,9 @@ int conv_fast(const ConvArgs &a, int N, int kh, int kw, hipStream_t s);
 // returns CT_OK / an error, or 1 if the geometry is not this kernel's
 int conv_ws(const ConvArgs &a, int N, bool gen, hipStream_t s);
 
+// conv_wino.hip / conv_wino4.hip: the same convolution as Winograd F(2x2, 3x3) on two fp16 pieces (weights packed by
+// ct_hip.pack_conv_weight_wino16); 1 = not this kernel's geometry
+int conv_wino(const ConvArgs &a, int N, hipStream_t s);
+int conv_wino4(const ConvArgs &a, int N, hipStream_t s);
+
 }  // namespace ct

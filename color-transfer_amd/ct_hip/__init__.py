@@ -18,7 +18,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CT_HIP_LIB") or os.path.join(_HERE, "libct_hip.so")   # CT_HIP_LIB: tuning builds only
 
-CT_ABI_VERSION = 8            # include/ct_hip.h: CT_ABI_VERSION; lib() refuses any other library
+CT_ABI_VERSION = 9            # include/ct_hip.h: CT_ABI_VERSION; lib() refuses any other library
 CT_LAB_STATS_STRIDE = 8
 CT_RGB_STATS_STRIDE = 16
 CT_WS_LAB_STATS, CT_WS_RGB_MEANCOV, CT_WS_REINHARD, CT_WS_IDT, CT_WS_REINHARD_PSNR, CT_WS_REINHARD_PERSIST = 0, 1, 2, 3, 4, 5
@@ -731,6 +731,12 @@ def conv_wino():
     return _wino
 
 
+def set_conv_wino_form(form):
+    """Which Winograd kernel ct_conv3x3_wino16_f32 launches (include/ct_hip.h: ct_set_conv_wino_form): 0 = the four-wave pipelined
+    kernel of round 6 (csrc/conv_wino4.hip, default), 1 = the eight-wave kernel of round 5 (csrc/conv_wino.hip)."""
+    check(lib().ct_set_conv_wino_form(int(form)))
+
+
 def _ws16_ok(x, split, kh, kw):
     return _ws16 and (kh, kw) == (3, 3) and 32 < x.shape[1] <= 64 and len(split) > 2 and split[2] is not None
 
@@ -958,6 +964,7 @@ SIGNATURES.update({
     "ct_conv2d_split_rows_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 7 + [_c_ll, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "ct_conv3x3_ws16_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p] + [_c_int] * 5 + [_c_ll, _c_ll, _c_ll, _c_int, _c_int, _c_p]),
     "ct_conv3x3_wino16_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p] + [_c_int] * 5 + [_c_ll, _c_ll, _c_ll, _c_int, _c_int, _c_p]),
+    "ct_set_conv_wino_form": (_c_int, [_c_int]),
     "ct_instance_norm_workspace_bytes": (ctypes.c_size_t, [_c_int]),
     "ct_instance_norm_f32": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_f, _c_int, _c_p, ctypes.c_size_t, _c_p]),
     "ct_eltwise_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_f, _c_p]),

@@ -37,7 +37,7 @@ extern "C" {
  * 5: ct_reinhard_persist_*, ct_reinhard_psnr_u8, CT_WS_REINHARD_PERSIST; 6: ct_conv2d_split_f32 gained scratch / scratch_bytes;
  * 7: ct_device_status);
  * the ctypes binding refuses a library whose ct_abi_version() differs */
-#define CT_ABI_VERSION 8
+#define CT_ABI_VERSION 9
 
 /* doubles per image in a stats record written by ct_lab_stats / ct_rgb_meancov */
 #define CT_LAB_STATS_STRIDE 8  /* mean[3], std[3] (population, ddof 0), n, 0           */
@@ -332,6 +332,13 @@ int ct_conv3x3_ws16_f32(const float *in, const void *wp16, int w_exp, const floa
 int ct_conv3x3_wino16_f32(const float *in, const void *wq16, int w_exp, const float *bias, const float *residual, float *out, int n,
                           int cin, int cout, int h, int w, long long in_bstride, long long out_bstride, long long res_bstride, int act,
                           int clamp, void *stream);
+/* Which kernel ct_conv3x3_wino16_f32 launches (new in ABI 9; process-wide, atomic; env CT_HIP_WINO_FORM=1 presets 1):
+ *   0 (default)  csrc/conv_wino4.hip: four waves of 512 registers per CU, the transformed weights in the accumulation registers, the
+ *                input transform of the next two output rows inside the matrix phase of the current ones (images of 64 * h * w * 4
+ *                bytes below 2^30; larger ones take form 1 by themselves);
+ *   1            csrc/conv_wino.hip: the eight-wave, three-phase kernel of round 5.
+ * Both are float32-grade and deterministic; they sum the sixteen positions in different orders, so they agree to rounding, not bitwise. */
+int ct_set_conv_wino_form(int form);
 
 /* Parallax attention, one direction (pasmnet/attention.py:39-41, utils.py:30, utils.py:123-125):
  *   P = softmax_j( sum_c q[c][h][i] k[c][h][j] / c ) ;  out_v[c][h][i] = sum_j P[i][j] v[c][h][j],

@@ -30,8 +30,8 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "library does not export %s" % name
     # the ctypes signature table binds exactly the declared entry points
     assert sorted(ct_hip.SIGNATURES.keys()) == declared
-    assert ct_hip.lib().ct_abi_version() == ct_hip.CT_ABI_VERSION == 8
-    assert re.search(r"#define CT_ABI_VERSION 8\b", open(HEADER).read())
+    assert ct_hip.lib().ct_abi_version() == ct_hip.CT_ABI_VERSION == 9
+    assert re.search(r"#define CT_ABI_VERSION 9\b", open(HEADER).read())
     assert ct_hip.lib().ct_error_string(-2).decode().startswith("workspace")
     assert ct_hip.lib().ct_workspace_bytes(ct_hip.CT_WS_REINHARD, 1920 * 1080, 4) > 0
     assert ct_hip.lib().ct_idt_workspace_bytes(1, 4, 255) > 0

@@ -85,12 +85,20 @@ def test_conv_ws_writes_only_its_output(hip, cfg):
     assert (out.double().cpu() - ref).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item())
 
 
+@pytest.fixture(params=[0, 1], ids=["wino4", "wino8"])
+def wino_form(hip, request):
+    """both Winograd kernels behind ct_conv3x3_wino16_f32: 0 = csrc/conv_wino4.hip (four waves, pipelined; the default), 1 = csrc/conv_wino.hip"""
+    hip.set_conv_wino_form(request.param)
+    yield request.param
+    hip.set_conv_wino_form(0)
+
+
 WINO_CASES = [(2, 64, 64, 24, 64), (1, 64, 32, 9, 36), (1, 48, 64, 50, 100), (1, 33, 7, 5, 8), (2, 64, 130, 41, 64), (3, 64, 64, 17, 32),
               (1, 64, 64, 2, 4), (1, 40, 64, 1, 12)]
 
 
 @pytest.mark.parametrize("cfg", WINO_CASES)
-def test_conv_wino_vs_float64(hip, cfg):
+def test_conv_wino_vs_float64(hip, cfg, wino_form):
     """ct_conv3x3_wino16_f32 (csrc/conv_wino.hip: Winograd F(2x2, 3x3) on two fp16 pieces) against the float64 convolution: odd
     heights (half tile rows), widths that are not multiples of the 32-column strip, partial channel groups, several images and
     segments, activation / skip / clamp; and nothing outside the output view is written."""
@@ -120,7 +128,7 @@ def test_conv_wino_vs_float64(hip, cfg):
         hip.set_conv_wino(False)
 
 
-def test_conv_wino_random_shapes(hip):
+def test_conv_wino_random_shapes(hip, wino_form):
     """30 seeded random geometries (heights 1..70, widths 4..132 in steps of 4, 33..64 input channels, 1..130 output channels,
     1..3 images, every activation the entry takes, with and without skip / clamp) against the float64 convolution"""
     rs = np.random.RandomState(7)
@@ -150,7 +158,7 @@ def test_conv_wino_random_shapes(hip):
         hip.set_conv_wino(False)
 
 
-def test_conv_wino_graph_replay_and_second_stream(hip):
+def test_conv_wino_graph_replay_and_second_stream(hip, wino_form):
     """the Winograd kernel allocates nothing and keeps no host state: captured in a graph and replayed, and launched on a second
     stream, it gives the eager result bit for bit"""
     n, cin, cout, h, w = 2, 64, 64, 30, 64
