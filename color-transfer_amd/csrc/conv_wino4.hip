@@ -41,7 +41,7 @@ constexpr size_t kLds = 2 * (size_t)kVWords * 4 + 16384 + 128;    // two images 
 
 // ---- the vector work of the two phases as flat lists of small operations; a phase is cut into 48 slices of about equal weight
 // (weight ~ instructions), one slice behind each MFMA -------------------------------------------------------------------------------
-enum : int { OP_W, OP_V, OP_H0, OP_H1, OP_L0, OP_L1, OP_SH, OP_SL, OP_LD,          // input transform of step s + 1
+enum : int { OP_W, OP_V, OP_H0, OP_H1, OP_L0, OP_L1, OP_SH, OP_SL, OP_CP, OP_LD, OP_SK,   // input transform of step s + 1; OP_SK: skip-row request
              OP_TAIL,                                                              // M A of cout blocks 0, 1 (accumulators of phase Y)
              OP_RD, OP_YA, OP_EP, OP_ST };                                         // output side of step s
 struct Op { int kind, r, a, b, c, wt; };
@@ -52,30 +52,86 @@ constexpr void push(Prog &p, int kind, int r, int a, int b, int c, int wt = 1) {
     p.op[p.n].kind = kind; p.op[p.n].r = r; p.op[p.n].a = a; p.op[p.n].b = b; p.op[p.n].c = c; p.op[p.n].wt = wt;
     ++p.n; p.wsum += wt;
 }
-// phase X: M A of blocks 0, 1 first (their MFMAs ran in phase Y of the previous step); then per role: all of B^T d (the registers of
-// patch rows 0, 1 are dead after it: the pair after next is requested into them, as early as possible), then V row by V row:
-// (B^T d) B, hi, lo, stores
-constexpr Prog make_prog_x() {
+// Spacing of the load instructions: the four waves of a workgroup run in lockstep, a 1 KB load occupies the CU's address path for 16
+// cycles, and a wave that issues into a busy path waits (tools/ubench/vmem_issue.hip: back to back, every load costs every wave ~64
+// cycles of issue) -- they are dealt into the arithmetic ONE AT A TIME, at least kGap weight units apart.
+constexpr int kGap = 16;
+// m: arithmetic in order; q: loads in order, each with the first position of m it may take (in .wt)
+constexpr Prog merge_spaced(const Prog &m, const Prog &q) {
     Prog p{};
-    for (int ml = 0; ml < 2; ++ml)
-        for (int i = 0; i < 4; ++i) push(p, OP_TAIL, 0, ml, i, 0, 6);
-    for (int r = 0; r < 2; ++r) {
-        for (int i = 0; i < 4; ++i)
-            for (int e = 0; e < 2; ++e)
-                for (int c = 0; c < 4; ++c) push(p, OP_W, r, e, i, c);
-        for (int e = 0; e < 2; ++e)
-            for (int row = 0; row < 2; ++row) push(p, OP_LD, r, e, row, 0);
-        for (int i = 0; i < 4; ++i) {
-            for (int e = 0; e < 2; ++e)
-                for (int c = 0; c < 4; ++c) push(p, OP_V, r, e, i, c);
-            for (int c = 0; c < 4; ++c) push(p, OP_H0, r, 4 * i + c, 0, 0);
-            for (int c = 0; c < 4; ++c) push(p, OP_H1, r, 4 * i + c, 0, 0);
-            for (int c = 0; c < 4; ++c) push(p, OP_L0, r, 4 * i + c, 0, 0);
-            for (int c = 0; c < 4; ++c) push(p, OP_L1, r, 4 * i + c, 0, 0);
-            for (int c = 0; c < 4; ++c) { push(p, OP_SH, r, 4 * i + c, 0, 0); push(p, OP_SL, r, 4 * i + c, 0, 0); }
+    int qi = 0, since = kGap;                   // weight since the last load
+    for (int i = 0; i < m.n; ++i) {
+        if (qi < q.n && i >= q.op[qi].wt && since >= kGap) {
+            push(p, q.op[qi].kind, q.op[qi].r, q.op[qi].a, q.op[qi].b, q.op[qi].c, 1);
+            ++qi; since = 0;
         }
+        push(p, m.op[i].kind, m.op[i].r, m.op[i].a, m.op[i].b, m.op[i].c, m.op[i].wt);
+        since += m.op[i].wt;
     }
+    for (; qi < q.n; ++qi) push(p, q.op[qi].kind, q.op[qi].r, q.op[qi].a, q.op[qi].b, q.op[qi].c, 1);
     return p;
+}
+// The input transform of a step in two parts.
+// Part W (runs in phase Y of the step BEFORE the one that finishes it): what frees the registers of patch rows 0, 1, so that the
+// requests for the pair after next go out a whole step before they are needed: role 0: all of B^T d; role 1: row 0 of B^T d and a
+// COPY of patch row 1 (8 moves; rows 1-3 of B^T d read the copy in part R: 16 registers held across the phases instead of 32).
+constexpr void push_part_w(Prog &m, Prog &q) {
+    for (int i = 0; i < 4; ++i)
+        for (int e = 0; e < 2; ++e)
+            for (int c = 0; c < 4; ++c) push(m, OP_W, 0, e, i, c);
+    for (int e = 0; e < 2; ++e)
+        for (int row = 0; row < 2; ++row) push(q, OP_LD, 0, e, row, 0, m.n);
+    for (int e = 0; e < 2; ++e)
+        for (int c = 0; c < 4; ++c) { push(m, OP_W, 1, e, 0, c); push(m, OP_CP, 1, e, c, 0); }
+    for (int e = 0; e < 2; ++e)
+        for (int row = 0; row < 2; ++row) push(q, OP_LD, 1, e, row, 0, m.n);
+}
+// Part R: V row by V row: (B^T d) B, hi, lo, stores
+constexpr void push_rows(Prog &p, int r) {
+    for (int i = 0; i < 4; ++i) {
+        for (int e = 0; e < 2; ++e)
+            for (int c = 0; c < 4; ++c) push(p, OP_V, r, e, i, c);
+        for (int c = 0; c < 4; ++c) push(p, OP_H0, r, 4 * i + c, 0, 0);
+        for (int c = 0; c < 4; ++c) push(p, OP_H1, r, 4 * i + c, 0, 0);
+        for (int c = 0; c < 4; ++c) push(p, OP_L0, r, 4 * i + c, 0, 0);
+        for (int c = 0; c < 4; ++c) push(p, OP_L1, r, 4 * i + c, 0, 0);
+        for (int c = 0; c < 4; ++c) { push(p, OP_SH, r, 4 * i + c, 0, 0); push(p, OP_SL, r, 4 * i + c, 0, 0); }
+    }
+}
+constexpr void push_part_r(Prog &m) {
+    push_rows(m, 0);
+    for (int i = 1; i < 4; ++i)
+        for (int e = 0; e < 2; ++e)
+            for (int c = 0; c < 4; ++c) push(m, OP_W, 1, e, i, c);
+    push_rows(m, 1);
+}
+// part W with its loads right where they may go (prologue: nothing to interleave with); with_r: the whole transform
+constexpr Prog make_prog_t(bool with_r) {
+    Prog m{}, q{};
+    push_part_w(m, q);
+    Prog p{};
+    for (int i = 0; i <= m.n; ++i) {
+        for (int j = 0; j < q.n; ++j)
+            if (q.op[j].wt == i) push(p, OP_LD, q.op[j].r, q.op[j].a, q.op[j].b, 0, 1);
+        if (i < m.n) push(p, m.op[i].kind, m.op[i].r, m.op[i].a, m.op[i].b, m.op[i].c, 1);
+    }
+    if (with_r) push_part_r(p);
+    return p;
+}
+// phase X: M A of blocks 0, 1 first (their MFMAs ran in phase Y of the previous step), then the input transform of step s + 1 with
+// the step's twelve load instructions dealt in: the requests for the pair after next as early as part W allows (they have to be back
+// by the end of this step), then those for the skip rows of this step's outputs (used in phase Y).
+// (Tried: part W and its requests in phase Y of the step before, a whole step of lead for the loads: 7100 -> 8700 cycles per step --
+// twelve memory instructions in the short slices of phase Y; profiles/r06_conv_wino4_ablations.txt.)
+constexpr Prog make_prog_x(bool has_res) {
+    Prog m{}, q{};
+    for (int ml = 0; ml < 2; ++ml)
+        for (int i = 0; i < 4; ++i) push(m, OP_TAIL, 0, ml, i, 0, 6);
+    push_part_w(m, q);
+    if (has_res)
+        for (int i = 0; i < 4; ++i) push(q, OP_SK, i >> 1, i & 1, 0, 0, m.n);
+    push_part_r(m);
+    return merge_spaced(m, q);
 }
 // phase Y: k = 0, 1: the thread's cout of blocks (mh, mh + 2); all LDS reads first, then per cout: A^T (M A), epilogue, stores
 constexpr Prog make_prog_y() {
@@ -93,7 +149,7 @@ constexpr Prog make_prog_y() {
     }
     return p;
 }
-constexpr Prog kProgX = make_prog_x(), kProgY = make_prog_y();
+constexpr Prog kProgX0 = make_prog_x(false), kProgX1 = make_prog_x(true), kProgY = make_prog_y(), kProgT0 = make_prog_t(true);
 // operations [lo, hi) of slice C of NCH: cut where the running weight crosses C / NCH of the total
 constexpr int slice_lo(const Prog &p, int C, int NCH) {
     int acc = 0;
@@ -110,6 +166,7 @@ struct St {
     f32x4 acc[4][2];               // [j][cout block of the pass]
     u32x4 bq[2][2];                // B fragments [cin chunk][piece] of the position in flight
     float w[2][4][4], v[2][4][4];  // B^T d, (B^T d) B of the role in flight
+    float d1c[2][4], w0b[2][4];    // role 1: copy of patch row 1, row 0 of B^T d taken early (see make_prog_x)
     unsigned int hw[16], lw[16];
     float scale;
     f32x2 tq[2][4][2];             // phase Y: (M A)[w][b] of two tiles, for the thread's two couts
@@ -130,7 +187,7 @@ struct Ctx {
     unsigned int *vb0, *vb1;        // V image word of this thread's T role: + ((p 2 + kc) 2 + piece) 256
     float *mxw;                     // M A of blocks 0, 1, this wave's part: + ((b 2 + ml) 4 + i) 64
     const float *mxr, *mr0;         // phase Y reads: blocks 0, 1: + w 1024 + b 512; blocks 2, 3 (in place): + PAR kVWords + w 4096 + b 512
-    __amdgpu_buffer_rsrc_t out_rs;
+    __amdgpu_buffer_rsrc_t out_rs, res_rs;
     unsigned int sto[2];            // byte offset of (cout k, first column) in this group's planes, or 2^31 (out of range)
     float bias[2];
     int act;
@@ -148,19 +205,21 @@ __device__ __forceinline__ void do_op(St &st, const Ctx &cx, const LoadF &load_r
 #ifdef W4_ABL_NO_LD
     if constexpr (o.kind == OP_LD) return;
 #endif
-    auto d = [&](int e, int i, int c) -> float { return i < 2 ? st.P[TP][r][e][i][c] : st.P[TP ^ 1][r][e][i - 2][c]; };
+    auto d = [&](int e, int i, int c) -> float { return i < 2 ? ((r == 1 && i == 1) ? st.d1c[e][c] : st.P[TP][r][e][i][c]) : st.P[TP ^ 1][r][e][i - 2][c]; };
     if constexpr (o.kind == OP_W) {
         constexpr int e = o.a, i = o.b, c = o.c;
-        if constexpr (i == 0) st.w[e][0][c] = d(e, 0, c) - d(e, 2, c);
+        if constexpr (i == 0 && r == 1) st.w0b[e][c] = d(e, 0, c) - d(e, 2, c);
+        else if constexpr (i == 0) st.w[e][0][c] = d(e, 0, c) - d(e, 2, c);
         else if constexpr (i == 1) st.w[e][1][c] = d(e, 1, c) + d(e, 2, c);
         else if constexpr (i == 2) st.w[e][2][c] = d(e, 2, c) - d(e, 1, c);
         else st.w[e][3][c] = d(e, 1, c) - d(e, 3, c);
     } else if constexpr (o.kind == OP_V) {
         constexpr int e = o.a, i = o.b, c = o.c;
-        if constexpr (c == 0) st.v[e][i][0] = st.w[e][i][0] - st.w[e][i][2];
-        else if constexpr (c == 1) st.v[e][i][1] = st.w[e][i][1] + st.w[e][i][2];
-        else if constexpr (c == 2) st.v[e][i][2] = st.w[e][i][2] - st.w[e][i][1];
-        else st.v[e][i][3] = st.w[e][i][1] - st.w[e][i][3];
+        auto w = [&](int cc) -> float { return (r == 1 && i == 0) ? st.w0b[e][cc] : st.w[e][i][cc]; };
+        if constexpr (c == 0) st.v[e][i][0] = w(0) - w(2);
+        else if constexpr (c == 1) st.v[e][i][1] = w(1) + w(2);
+        else if constexpr (c == 2) st.v[e][i][2] = w(2) - w(1);
+        else st.v[e][i][3] = w(1) - w(3);
     } else if constexpr (o.kind == OP_H0) {     // hi = fp16(v 2^ex): the scale rides in the converting fma; one half of the word each
         constexpr int p = o.a;
         asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(st.hw[p]) : "v"(st.v[0][p >> 2][p & 3]), "v"(st.scale));
@@ -187,9 +246,15 @@ __device__ __forceinline__ void do_op(St &st, const Ctx &cx, const LoadF &load_r
 #else
         asm volatile("" :: "v"(st.lw[p]));
 #endif
+    } else if constexpr (o.kind == OP_CP) {
+        constexpr int e = o.a, c = o.b;
+        st.d1c[e][c] = st.P[TP][1][e][1][c];
     } else if constexpr (o.kind == OP_LD) {     // the row pair after next into the registers of pair t
         constexpr int e = o.a, row = o.b;
         load_row(r, e, row, st.P[TP][r][e][row]);
+    } else if constexpr (o.kind == OP_SK) {     // one skip row (ro0 / ro1: the byte offsets of this step's two output rows, clamped into the image)
+        constexpr int k = o.r, a = o.a;
+        st.rq[k][a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cx.res_rs, (int)(cx.sto[k] + (a ? ro1 : ro0)), 0, 0));
     } else if constexpr (o.kind == OP_TAIL) {   // M A in the accumulators' lanes: b = 0: m0 + m1 + m2, b = 1: m1 - m2 - m3 (unscaled in phase Y)
         constexpr int ml = o.a, i = o.b;
 #ifndef W4_ABL_NO_TAIL
@@ -312,9 +377,9 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wino4_kernel(ConvArgs a, int
         float *out = a.out + (size_t)nimg * a.out_bstride + (size_t)grp * 64 * plane;
         const int cout_g = min(a.cout - grp * 64, 64);
         cx.out_rs = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((unsigned int)cout_g * uplane * 4u), 0x00020000);
-        __amdgpu_buffer_rsrc_t res_rs = cx.out_rs;
+        cx.res_rs = cx.out_rs;
         if constexpr (HAS_RES)
-            res_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.residual + (size_t)nimg * a.res_bstride + (size_t)grp * 64 * plane), 0,
+            cx.res_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.residual + (size_t)nimg * a.res_bstride + (size_t)grp * 64 * plane), 0,
                                                        (int)((unsigned int)cout_g * uplane * 4u), 0x00020000);
 
         // ---- input patches: role r, channel 2 (16 r + 4 wave + cq) + e, columns x0 + 2 tt - 1 .. + 2, always an in-bounds 16-byte load ----
@@ -469,7 +534,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wino4_kernel(ConvArgs a, int
         st.scale = __uint_as_float((unsigned int)(127 + ex_next) << 23);
         {
             auto ld = [&](int r, int e, int row, float (&dst)[4]) { load_pair_row(2, r, e, row, dst); };
-            do_ops<ACTK, HAS_RES, 0, 0, kProgX, 8>(st, cx, ld, 0.f, 0u, 0u, std::make_integer_sequence<int, kProgX.n - 8>());     // without the 8 OP_TAIL
+            do_ops<ACTK, HAS_RES, 0, 0, kProgT0, 0>(st, cx, ld, 0.f, 0u, 0u, std::make_integer_sequence<int, kProgT0.n>());
         }
         finish_pair(2, st.P[0]);
         __syncthreads();
@@ -484,13 +549,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wino4_kernel(ConvArgs a, int
             const int ex = ex_next;
             const f32x4 mxa = max_of(s + 1), mxb = max_of(s + 2);
             touch_pair(s + 4);
-            // the skip rows of this step's outputs come from HBM, once: requested a matrix phase ahead of their use, ONE per slice (a
-            // burst of vector memory instructions stalls the wave's issue for ~100-200 cycles each, a lone one for far less)
-            auto skip_request = [&](auto i_c) {
-                constexpr int k = decltype(i_c)::value >> 1, r = decltype(i_c)::value & 1;
-                if constexpr (HAS_RES)
-                    st.rq[k][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, (int)(cx.sto[k] + (unsigned int)(min(oy + r, a.H - 1) * a.W) * 4u), 0, 0));
-            };
+            const unsigned int sk0 = (unsigned int)(min(oy, a.H - 1) * a.W) * 4u, sk1 = (unsigned int)(min(oy + 1, a.H - 1) * a.W) * 4u;
             first_frags(PAR);          // position 0 again: the second pass re-reads the fragments (its accumulators are the first pass's)
             auto ld = [&](int r, int e, int row, float (&dst)[4]) { load_pair_row(s + 3, r, e, row, dst); };
             // ---------------- phase X: cout blocks 2, 3 of step s; M A of blocks 0, 1; T(s + 1) ----------------
@@ -498,23 +557,21 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wino4_kernel(ConvArgs a, int
             W4_STAMP(0);
             for_each_c([&](auto c_c) {
                 constexpr int C = decltype(c_c)::value;
-                constexpr int lo = slice_lo(kProgX, C, 48), hi = slice_lo(kProgX, C + 1, 48);
+                constexpr const Prog &PX = HAS_RES ? kProgX1 : kProgX0;
+                constexpr int lo = slice_lo(PX, C, 48), hi = slice_lo(PX, C + 1, 48);
                 // the first pass's accumulators are read by the OP_TAIL operations, which lead the program: the second pass's MFMAs
                 // start behind them (slices that still hold an OP_TAIL get no MFMA; they are made up for at the end)
-                constexpr int first = slice_lo(kProgX, 0, 48);
-                (void)first;
-                constexpr int n_tail_slices = [] { int c = 0; while (slice_lo(kProgX, c, 48) < 8) ++c; return c; }();
+                constexpr int n_tail_slices = [] { int c = 0; while (slice_lo(HAS_RES ? kProgX1 : kProgX0, c, 48) < 8) ++c; return c; }();
                 if constexpr (C >= n_tail_slices) mfma(std::integral_constant<int, 1>(), par_c, std::integral_constant<int, C - n_tail_slices>());
-                if constexpr (C == 1 || C == 3 || C == 5 || C == 7) skip_request(std::integral_constant<int, (C - 1) / 2>());
                 if constexpr (C == 6) {
                     ex_next = ex_of(mxa, mxb);
                     st.scale = __uint_as_float((unsigned int)(127 + ex_next) << 23);
                 }
-                do_ops<ACTK, HAS_RES, PAR ^ 1, PAR, kProgX, lo>(st, cx, ld, 0.f, 0u, 0u, std::make_integer_sequence<int, hi - lo>());
+                do_ops<ACTK, HAS_RES, PAR ^ 1, PAR, PX, lo>(st, cx, ld, 0.f, sk0, sk1, std::make_integer_sequence<int, hi - lo>());
                 __builtin_amdgcn_sched_barrier(0);
             }, std::make_integer_sequence<int, 48>());
             {
-                constexpr int n_tail_slices = [] { int c = 0; while (slice_lo(kProgX, c, 48) < 8) ++c; return c; }();
+                constexpr int n_tail_slices = [] { int c = 0; while (slice_lo(HAS_RES ? kProgX1 : kProgX0, c, 48) < 8) ++c; return c; }();
                 for_each_c([&](auto c_c) { mfma(std::integral_constant<int, 1>(), par_c, std::integral_constant<int, 48 - n_tail_slices + decltype(c_c)::value>()); },
                            std::make_integer_sequence<int, n_tail_slices>());
             }
