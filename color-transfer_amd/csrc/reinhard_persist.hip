@@ -47,6 +47,9 @@ namespace rp {
 #endif
 #define CT_RP_PIXEL_FENCE(q) do { if (((q) + 1) % CT_RP_ILP == 0) __builtin_amdgcn_sched_barrier(0); } while (0)
 
+#ifndef CT_RP_F32_WAVES
+#define CT_RP_F32_WAVES 16
+#endif
 constexpr int kMaxWaves = 16;                     // waves per workgroup: 16 (4 per SIMD, 128 registers each) or 8 (256 registers)
 constexpr int kTileBytes = kTilePixels * 12;      // a parked tile: 3 dwords per pixel
 constexpr int kShards = 8;
@@ -779,25 +782,53 @@ size_t ws_bytes(int64_t n_pixels, int batch) {
     return n;
 }
 
+// The launch chain of a device (see launch()): ONE for all instantiations -- a float32 launch on one stream and a uint8 launch on
+// another starve each other exactly like two launches of the same type (round 5 kept these as function-local statics of the
+// template, i.e. one chain per element type).
+static std::mutex g_chain_mutex;
+static hipEvent_t g_chain_event[kMaxDevices];
+static hipStream_t g_chain_stream[kMaxDevices];
+
+// waves per workgroup of the float32 instantiation: 16 (4 per SIMD, 128 registers: 54 of them spilled) or 8 (2 per SIMD, 256
+// registers, nothing spilled); CT_HIP_PERSIST_WAVES presets it (tuning)
+static int f32_waves() {
+    static const int v = [] { const char *e = getenv("CT_HIP_PERSIST_WAVES"); const int x = e ? atoi(e) : 0; return x == 8 || x == 16 ? x : CT_RP_F32_WAVES; }();
+    return v;
+}
+
 template <typename T>
 int launch(const T *target, const T *reference, const T *gt, float *out, double *psnr_out, int64_t n_pixels, int batch, double *stats_out,
            void *ws, size_t ws_size, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (!eligible(n_pixels, true)) return CT_E_BADARG;
     if (ws == nullptr || (reinterpret_cast<uintptr_t>(ws) & 15) || ws_size < ws_bytes(n_pixels, batch)) return CT_E_WORKSPACE;
     if (gt != nullptr && psnr_out == nullptr) return CT_E_BADARG;
+    {   // out must not overlap an input frame: the exact redo of a flagged tile re-reads the input after the fast result is stored
+        const uintptr_t o0 = reinterpret_cast<uintptr_t>(out), o1 = o0 + (size_t)batch * n_pixels * 3 * sizeof(float);
+        const size_t in_bytes = (size_t)batch * n_pixels * 3 * sizeof(T);
+        for (const T *q : {target, reference, gt}) {
+            const uintptr_t q0 = reinterpret_cast<uintptr_t>(q);
+            if (q != nullptr && q0 < o1 && o0 < q0 + in_bytes) return CT_E_BADARG;
+        }
+    }
     const int g = grid_size();
     const int slots = slots_for(n_pixels);
     const int pslots = slots < kMaxParked ? slots : kMaxParked;
     const size_t lds = (size_t)kLdsFixed + (size_t)2 * pslots * kTileBytes;
     // 16 waves per workgroup (4 per SIMD, 128 registers).  The kernel is a template on the wave count: the 8-wave form (256 registers,
     // no spills) measured 28.5 - 35.9 k pairs/s against 34.2 - 34.5 k on float32 frames and is not instantiated.
-    constexpr int waves = kMaxWaves;
+    int waves = kMaxWaves;
     void (*kern)(const Args) = gt ? reinhard_persist_kernel<T, true, kMaxWaves> : reinhard_persist_kernel<T, false, kMaxWaves>;
-    // function attributes are per device: cached per (device, instantiation of this template (T) x gt)
-    static DynLdsAttr attr[2];
+    if constexpr (sizeof(T) == 4) {
+        if (f32_waves() == 8) {
+            waves = 8;
+            kern = gt ? reinhard_persist_kernel<T, true, 8> : reinhard_persist_kernel<T, false, 8>;
+        }
+    }
+    // function attributes are per device: cached per (device, instantiation of this template (T) x gt x wave count)
+    static DynLdsAttr attr[4];
     const int dev = current_device();
     {
-        hipError_t e = attr[gt ? 1 : 0].ensure(reinterpret_cast<const void *>(kern), kLdsMax);
+        hipError_t e = attr[(gt ? 1 : 0) + (waves == 8 ? 2 : 0)].ensure(reinterpret_cast<const void *>(kern), kLdsMax);
         if (e != hipSuccess) return (int)e;
     }
     // Two persistent launches must not share the GPU: each needs every one of its workgroups resident (one per CU, the CU's LDS to
@@ -809,10 +840,9 @@ int launch(const T *target, const T *reference, const T *gt, float *out, double 
     (void)hipStreamIsCapturing(stream, &cap);
     (void)hipGetLastError();
     const bool chain = cap == hipStreamCaptureStatusNone;
-    static std::mutex chain_mutex;
-    static hipEvent_t chain_event[kMaxDevices];
-    static hipStream_t chain_stream[kMaxDevices];
-    std::unique_lock<std::mutex> chain_lock(chain_mutex, std::defer_lock);
+    hipEvent_t *const chain_event = g_chain_event;
+    hipStream_t *const chain_stream = g_chain_stream;
+    std::unique_lock<std::mutex> chain_lock(g_chain_mutex, std::defer_lock);
     if (chain) {
         chain_lock.lock();
         if (chain_event[dev] == nullptr) {

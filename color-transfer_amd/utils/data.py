@@ -215,23 +215,33 @@ class SyntheticStereoVideoU8:
     def __len__(self):
         return self.n_frames
 
-    def _pool(self):
+    def _chunk(self, i):
+        """pinned chunk i of the pool, generated on first use (a run that touches two chunks pins two: 149 MB each at 1080p)"""
         if self._chunks is None:
-            self._chunks = []
-            for i in range(self.pool):
-                rng = np.random.default_rng(4321 + i)
-                trip = rng.integers(0, 256, (3, self.group, self.height, self.width, 3), dtype=np.uint8)
-                t = torch.from_numpy(trip)
-                self._chunks.append(t.pin_memory() if torch.cuda.is_available() else t)
-        return self._chunks
+            self._chunks = [None] * self.pool
+        if self._chunks[i] is None:
+            rng = np.random.default_rng(4321 + i)
+            trip = rng.integers(0, 256, (3, self.group, self.height, self.width, 3), dtype=np.uint8)
+            t = torch.from_numpy(trip)
+            self._chunks[i] = t.pin_memory() if torch.cuda.is_available() else t
+        return self._chunks[i]
+
+    def _pool_index(self, first_frame):
+        """which pool chunk a group that starts at `first_frame` takes: a multiplicative hash of the frame index, so that the pool
+        cycles whatever the stride between a rank's groups is (round 5 indexed by first_frame % pool: with group = pool = 8 every
+        group of a rank got the same chunk) -- a function of the frame index only, not of rank or world size"""
+        return ((int(first_frame) * 2654435761) >> 9) % self.pool
 
     def host_chunk(self, first_frame):
-        """the pinned chunk whose first frame is `first_frame` (frame f of the video = frame f of chunk pool[f % pool])"""
-        return self._pool()[first_frame % self.pool]
+        """the pinned chunk of the group of frames that starts at `first_frame`.  Synthetic data: a group's CONTENT is defined by its
+        first frame (chunk _pool_index(first_frame), slots 0..group-1 in order), so per-frame tables depend on how frames are
+        grouped (group size, world size); throughput does not."""
+        return self._chunk(self._pool_index(first_frame))
 
     def __getitem__(self, f):
-        """one frame as the reference's sample dict (float32 CHW in [0,1]): the per-sample path of utils.cli"""
-        c = self._pool()[f % self.pool][:, 0]
+        """one frame as the reference's sample dict (float32 CHW in [0,1]): the per-sample path of utils.cli = a group of one
+        (slot 0 of the chunk host_chunk(f) would hand over)"""
+        c = self.host_chunk(f)[:, 0]
         return {k: (c[i].permute(2, 0, 1).float() / 255) for i, k in enumerate(self.roles)}
 
 

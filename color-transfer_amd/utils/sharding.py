@@ -43,28 +43,41 @@ def frame_seed(frame_index, base=1234):
     return base + int(frame_index)
 
 
-def gather_frame_metrics(local_metrics, n_frames, rank=None, world=None):
+def gather_frame_metrics(local_metrics, n_frames, rank=None, world=None, status=None):
     """local_metrics: [n_local, n_metrics] for frames_of_rank(...) in that order.
-    Returns [n_frames, n_metrics] in frame order on every rank (a single all_gather)."""
+    Returns [n_frames, n_metrics] in frame order on every rank (a single all_gather).
+    status: this rank's device status word (default: read from the device when the table lives there; tests pass it in)."""
     if world is None:
         world = dist.get_world_size() if dist.is_initialized() else 1
     if rank is None:
         rank = dist.get_rank() if dist.is_initialized() else 0
-    if local_metrics.is_cuda:
+    if status is not None:
+        status = int(status)
+    elif not local_metrics.is_cuda:
+        status = 0
+    else:
         # the one place a run that never synchronises per frame looks at the device's sticky status (include/ct_hip.h:
         # ct_device_status): a persistent launch / stream-K convolution that gave up a bounded spin left NaN / wrong frames
         import ct_hip
-        status = ct_hip.device_status(clear=True)
-        if status:
-            raise RuntimeError("rank %d: the HIP kernels reported status 0x%x (a launch gave up a bounded spin: results invalid)" % (rank, status))
+        status = int(ct_hip.device_status(clear=True))
     n_pad = padded_local_count(n_frames, world)
     n_metrics = local_metrics.shape[1]
-    buf = torch.full((n_pad, n_metrics), float("nan"), dtype=local_metrics.dtype, device=local_metrics.device)
+    # one extra row carries this rank's status through the SAME collective: a rank that raised before the gather would leave the
+    # others blocked in it until the backend's timeout (ADVICE r05); this way every rank sees every status and all raise together
+    buf = torch.full((n_pad + 1, n_metrics), float("nan"), dtype=local_metrics.dtype, device=local_metrics.device)
     buf[: local_metrics.shape[0]] = local_metrics
+    buf[n_pad] = float(status)
     if world == 1:
+        if status:
+            raise RuntimeError("rank %d: the HIP kernels reported status 0x%x (a launch gave up a bounded spin: results invalid)" % (rank, status))
         return buf[:n_frames]
-    out = torch.empty((world, n_pad, n_metrics), dtype=local_metrics.dtype, device=local_metrics.device)
-    dist.all_gather_into_tensor(out.view(world * n_pad, n_metrics), buf)
+    out = torch.empty((world, n_pad + 1, n_metrics), dtype=local_metrics.dtype, device=local_metrics.device)
+    dist.all_gather_into_tensor(out.view(world * (n_pad + 1), n_metrics), buf)
+    bad = [(r, int(v)) for r, v in enumerate(out[:, n_pad, 0].tolist()) if v == v and int(v) != 0]
+    if bad:
+        raise RuntimeError("rank %d: the HIP kernels reported a status on rank(s) %s (a launch gave up a bounded spin: results invalid)"
+                           % (rank, ", ".join("%d: 0x%x" % b for b in bad)))
+    out = out[:, :n_pad]
     # rank r, slot i  ->  frame r + i * world
     table = out.permute(1, 0, 2).reshape(world * n_pad, n_metrics)
     return table[:n_frames]

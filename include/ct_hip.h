@@ -130,9 +130,11 @@ int ct_reinhard_psnr_f32(const float *target, const float *reference, const floa
  * the whole frame, which travel between the workgroups as 64-bit integer atomics one pair ahead of their use (the rest of its
  * target tiles are fetched a second time); no launch boundary, no finishing kernels, one pass over the reference.
  * Frame sizes: 256 pixels .. 16 Mpixel (ct_reinhard_persist_supported).  Measured at 1080p, 16 pairs per call: float32 frames
- * 33 - 34 k pairs/s (the two sweeps of ct_reinhard_psnr_f32: 36.5 k -- both forms are bound by vector instruction issue and
- * this one executes more instructions, so the fused float32 entries keep the two sweeps unless CT_HIP_REINHARD_PERSIST=1);
- * uint8 frames 43 - 45 k pairs/s, which no other entry serves.
+ * 39 - 41 k pairs/s (the two sweeps of ct_reinhard_psnr_f32: 41.5 - 43.6 k -- this form is bound by vector instruction issue and
+ * executes more instructions, so the fused float32 entries keep the two sweeps unless CT_HIP_REINHARD_PERSIST=1);
+ * uint8 frames 46.6 - 49.4 k pairs/s, which no other entry serves.
+ * out must NOT overlap target, reference or gt (CT_E_BADARG): a tile with a pixel near a kink of the inverse is redone with the
+ * exact code from the input frame AFTER its fast-path result has been stored (the two-sweep entries above do allow out == target).
  * gt = NULL: no metric (psnr_out unused); else psnr_out[i] = {mse, PSNR} like ct_reinhard_psnr_f32.
  * ws: ct_workspace_bytes(CT_WS_REINHARD_PERSIST, n_pixels, batch).  After the call has completed, the first 32-bit word of
  * ws is 0, or 1 when a workgroup of the grid never became resident within 2 s (results are then NaN).

@@ -128,6 +128,36 @@ def test_conv_wino_vs_float64(hip, cfg, wino_form):
         hip.set_conv_wino(False)
 
 
+def test_conv_wino_1080p_bands_vs_float64(hip, wino_form):
+    """The size BASELINE.json's metric names (Missing 3): ONE 2-view 64 -> 64 launch at 1080 x 1920 with LeakyReLU and a
+    skip tensor (the second convolution of a ResB, reference pasmnet/backbone.py:8-15), held against the float64 convolution on 8-row
+    bands at the top, at every row-segment boundary of both kernels' decompositions (270 / 540 / 810 for the four-wave kernel) and at
+    the bottom, all 1920 columns (every strip, both image edges), both views.  Rows of mixed magnitude as in the network's activations."""
+    n, c, h, w = 2, 64, 1080, 1920
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, c, h, w, generator=g)
+    x[:, :, 200:600] *= 1e-2
+    wt, b = torch.randn(c, c, 3, 3, generator=g) / (c * 9) ** 0.5, torch.randn(c, generator=g)
+    res = torch.randn(n, c, h, w, generator=g)
+    wp, bp = hip.pack_conv_weight(wt.cuda(), b.cuda())
+    hip.set_conv_wino(True)
+    try:
+        out = hip.conv2d(x.cuda(), wp, bp, c, 3, act=1, residual=res.cuda()).cpu()
+    finally:
+        hip.set_conv_wino(False)
+    worst = 0.0
+    for y0 in (0, 132, 266, 536, 806, 944, 1072):
+        ya, yb = max(y0 - 1, 0), min(y0 + 9, h)                     # one halo row each side where the image has one
+        ref = F.leaky_relu(F.conv2d(x[:, :, ya:yb].double(), wt.double(), b.double(), padding=1), 0.01)
+        lo, hi = y0 - ya, y0 - ya + 8
+        want = ref[:, :, lo:hi] + res[:, :, y0:y0 + 8].double()
+        err = (out[:, :, y0:y0 + 8].double() - want).abs().max().item()
+        tol = 3e-6 * max(1.0, ref[:, :, lo:hi].abs().max().item())
+        worst = max(worst, err / tol)
+        assert err < tol, (wino_form, y0, err, tol)
+    print("conv_wino form %d at 1080p: worst band error %.2f of the tolerance" % (wino_form, worst))
+
+
 def test_conv_wino_random_shapes(hip, wino_form):
     """30 seeded random geometries (heights 1..70, widths 4..132 in steps of 4, 33..64 input channels, 1..130 output channels,
     1..3 images, every activation the entry takes, with and without skip / clamp) against the float64 convolution"""

@@ -117,3 +117,24 @@ def test_cli_on_the_artificial_grid(capsys):
     assert table.shape == (31, 4) and torch.isfinite(table).all()        # PSNR, SSIM, FSIM, iCID
     assert float(table[0, 0]) > float(table[1, 0]) - 50       # sanity: the identity sample is not worse than everything else
     assert "Test SSIM" in capsys.readouterr().out
+
+
+def test_synthetic_video_pool_cycles_for_every_stride():
+    """the pinned chunk a group takes is a hash of its first frame -- it cycles through the pool whatever the stride
+    between a rank's groups is (first_frame % pool handed every group of a rank the same chunk), chunks are made on first use, and the
+    per-frame path returns slot 0 of the chunk the grouped path would hand over for a group starting there"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "color-transfer_amd"))
+    from utils.data import SyntheticStereoVideoU8
+    ds = SyntheticStereoVideoU8(n_frames=1000, height=4, width=6, group=8, pool=8)
+    assert ds._chunks is None
+    for world in (1, 2, 8):
+        for rank in range(world):
+            firsts = [rank + world * 8 * c for c in range(32)]            # first frames of a rank's groups (frames rank, rank + world, ...)
+            used = {ds._pool_index(f) for f in firsts}
+            assert len(used) >= 6, (world, rank, used)
+    c = ds.host_chunk(64)
+    assert c.shape == (3, 8, 4, 6, 3) and c.dtype == torch.uint8
+    assert sum(x is not None for x in ds._chunks) == 1                    # only what was touched
+    f = ds[64]
+    assert torch.equal(f["target"], c[0, 0].permute(2, 0, 1).float() / 255) and torch.equal(f["gt"], c[2, 0].permute(2, 0, 1).float() / 255)

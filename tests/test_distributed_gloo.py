@@ -43,3 +43,32 @@ def test_two_rank_gather_matches_single_rank(tmp_path):
         got = torch.load(os.path.join(str(tmp_path), "table_%d.pt" % r))
         assert got.shape == (n_frames, 3)
         assert torch.equal(got, want)
+
+
+def _worker_status(rank, world, port, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "color-transfer_amd"))
+    from utils import sharding as sh
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    local = torch.zeros((len(sh.frames_of_rank(5, rank, world)), 2), dtype=torch.float64)
+    try:
+        sh.gather_frame_metrics(local, 5, status=1 if rank == 1 else 0)
+        msg = "no error"
+    except RuntimeError as e:
+        msg = str(e)
+    open(os.path.join(out_dir, "status_%d.txt" % rank), "w").write(msg)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_status_on_one_rank_raises_on_every_rank(tmp_path):
+    """the device status travels through the gather itself -- a rank that raised BEFORE the collective would leave the
+    others blocked in it until the backend's timeout; here rank 1 reports a status and both ranks raise, after the same collective"""
+    port = _free_port()
+    mp.spawn(_worker_status, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        msg = open(os.path.join(str(tmp_path), "status_%d.txt" % r)).read()
+        assert "status on rank(s) 1: 0x1" in msg, (r, msg)

@@ -68,3 +68,21 @@ def test_oracle_one_direction_vs_reference(golden_dir, tag, hw, seed):
 def test_inference_size_rule():
     assert og.derive_matcher_inference_size((1, 3, 540, 960)) == [512, 896]
     assert og.derive_matcher_inference_size((1, 3, 135, 240)) == [160, 256]
+
+
+def test_float64_anchors_belong_to_the_reference_fixtures(golden_dir):
+    """tests/golden/gmflow_f64.npz (make_golden_gmflow_f64.py: the oracle in float64 after it reproduced gmflow_small.npz in float32):
+    every stage of both pairs is there, and the stored distance d32 = max |reference float32 - float64| is what the two files give
+    (float64 values are stored to float32: 1e-7 relative).  No GPU: numpy on the two fixtures."""
+    import numpy as np
+    g = np.load(os.path.join(golden_dir, "gmflow_small.npz"), allow_pickle=False)
+    f = np.load(os.path.join(golden_dir, "gmflow_f64.npz"), allow_pickle=False)
+    keys = ["feat_s0_c16", "feat_s1_c16", "tf0_s0_c16", "flow_match_s0", "flow_prop_s0", "tf0_s1_c16", "flow_match_s1", "flow_prop_s1"]
+    keys += ["flow_refine_%d" % i for i in range(6)] + ["flow", "flow_bwd"]
+    for tag in ("a", "b"):
+        for k in keys:
+            ref, x64, d32 = g[tag + "/" + k].astype(np.float64), f[tag + "/" + k].astype(np.float64), float(f[tag + "/" + k + "/d32"])
+            assert ref.shape == x64.shape
+            d = float(np.abs(ref - x64).max())
+            assert abs(d - d32) <= 1e-6 * max(1.0, float(np.abs(ref).max())), (tag, k, d, d32)
+            assert 0 < d32 < 0.1, (tag, k, d32)            # float32 rounding through ~150 layers, not a different network

@@ -311,3 +311,45 @@ def test_two_streams_are_chained_and_status_is_clean(hip):
     for o, p in outs:
         assert torch.equal(o, want_o) and torch.equal(p, want_p)
     assert hip.device_status() == 0
+
+
+def test_two_streams_of_different_element_types_are_chained(hip):
+    """the launch chain is ONE per device, not one per element type -- a float32 launch on one stream and a uint8 launch
+    on another would starve each other exactly like two launches of one type.  Alternating types on two streams: every result is
+    that of the call run alone, nothing sits in a 2 s spin, the sticky status stays 0."""
+    import time
+    rng = np.random.default_rng(32)
+    t, r, g = (dev(rng.random((4, 1080, 1920, 3), dtype=np.float32)) for _ in range(3))
+    t8, r8, g8 = ((x * 255).round().to(torch.uint8) for x in (t, r, g))
+    want = [tuple(x.clone() for x in hip.reinhard_persist(a, b, gt=c, verify=True)) for a, b, c in ((t, r, g), (t8, r8, g8))]
+    assert hip.device_status(clear=True) == 0
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(4):
+        for k, s in enumerate((sa, sb)):
+            kind = (i + k) & 1                                  # both orders: f32 after u8 and u8 after f32, on either stream
+            with torch.cuda.stream(s):
+                outs.append((kind, hip.reinhard_persist(*((t, r), (t8, r8))[kind], gt=(g, g8)[kind])))
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 1.0
+    for kind, (o, p) in outs:
+        assert torch.equal(o, want[kind][0]) and torch.equal(p, want[kind][1])
+    assert hip.device_status() == 0
+
+
+def test_output_must_not_overlap_an_input(hip):
+    """include/ct_hip.h: a flagged tile is redone from the INPUT frame after its fast-path result has been stored, so the persistent
+    launch refuses an output that overlaps target / reference / gt (the two-sweep entries allow out == target)"""
+    rng = np.random.default_rng(33)
+    t, r = dev(rng.random((1, 64, 64, 3), dtype=np.float32)), dev(rng.random((1, 64, 64, 3), dtype=np.float32))
+    with pytest.raises(hip.CtHipError):
+        hip.reinhard_persist(t, r, out=t)
+    with pytest.raises(hip.CtHipError):
+        hip.reinhard_persist(t, r, out=r)
+    buf = torch.empty(2 * t.numel(), dtype=torch.float32, device="cuda")
+    buf[: t.numel()] = t.flatten()
+    with pytest.raises(hip.CtHipError):                          # a partial overlap
+        hip.reinhard_persist(buf[: t.numel()].view(t.shape), r, out=buf[t.numel() // 2: t.numel() // 2 + t.numel()].view(t.shape))
+    hip.reinhard_persist(t, r, verify=True)                      # and the plain call still runs
