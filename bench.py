@@ -39,6 +39,7 @@ H, W = 1080, 1920
 N_PIX = H * W
 PLANE_F32 = N_PIX * 3 * 4                    # 24 883 200 B
 ALGO_BYTES_PER_PAIR = 3 * PLANE_F32          # read target, read reference, write output
+PROFILE_ROUND = "r06"                         # profiles/<round>_*: quoted only when their source stamp is this tree's
 HBM_PEAK = 8.0e12                            # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
 BASELINE_METRIC = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
 # arithmetic the headline path computes in, per Lab mode (ct_set_lab_mode)
@@ -265,13 +266,13 @@ def main():
         # HBM traffic per launch of the dominant kernel from the committed PMC profile (separate --pmc passes,
         # FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md "HBM"), valid for the same pairs-per-step only
         traffic = None
-        tj = read_stamped(os.path.join(ROOT, "profiles", "r05_traffic.json"))     # None unless measured on THIS tree's kernel sources
+        tj = read_stamped(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_traffic.json"))     # None unless measured on THIS tree's kernel sources
         if tj and tj.get("pairs_per_step") == B and tj.get("lab_mode") == ct_hip.lab_mode():
             traffic = tj.get("hbm_bytes_per_launch", {}).get(dom)
         t_kernels = t_stats + t_apply
         roof = {"bound": "hbm", "kernel": dom, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": ach / HBM_PEAK, "traffic": traffic,
-                "traffic_source": ("profiles/r05_traffic.json (rocprofv3 --pmc passes of this command on a build with source stamp %s; not live)" % source_stamp()) if traffic
+                "traffic_source": ("profiles/" + PROFILE_ROUND + "_traffic.json (rocprofv3 --pmc passes of this command on a build with source stamp %s; not live)" % source_stamp()) if traffic
                 else "no PMC profile of this build under profiles/ (stamp %s)" % source_stamp(),
                 "algorithmic_bytes_per_launch": kern[dom]["bytes"],
                 "algorithmic_bytes_note": "2 float32 planes x %d pairs (SURVEY 8d): %s" % (
@@ -381,6 +382,26 @@ def main():
             # 0, reference in every histogram, apply 0 input) = 8 float32 planes of 24.9 MB + 10 float64 planes of 49.8 MB
             extra["idt_frac_hbm_peak_bytes_moved"] = (8 * 4 + 10 * 8) * 3 * H * W * idt / HBM_PEAK
             del idt_out
+            # the same two paths as roofline objects: bound, achieved, peak, and the counter traffic of their
+            # kernels from the committed profile of THIS build (null otherwise)
+            itj = read_stamped(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_idt_traffic.json")) or {}
+            idt_moved = (8 * 4 + 10 * 8) * 3 * H * W
+            idt_traffic = None
+            if itj.get("per_kernel"):
+                pk = itj["per_kernel"]
+                idt_traffic = {k: v.get("read_bytes_mean_per_launch", 0) + v.get("write_bytes_mean_per_launch", 0) for k, v in pk.items()}
+            extra["rooflines_other_paths"] = {
+                "idt": {"bound": "hbm", "achieved": idt_moved * idt / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": idt_moved * idt / HBM_PEAK,
+                        "bytes_per_pair": idt_moved, "pairs_per_s": idt,
+                        "bytes_note": "what the 14 launches of a call move per pair: 8 float32 + 10 float64 planes (SURVEY 8d's unfused figure is 920.7 MB: "
+                                      "frac %.3f on that)" % (920678400 * idt / HBM_PEAK),
+                        "traffic_mean_bytes_per_launch_by_kernel": idt_traffic,
+                        "traffic_source": ("profiles/%s_idt_traffic.json (separate --pmc passes, this build's stamp; launches of 1 and of 16 pairs mixed)" % PROFILE_ROUND)
+                        if idt_traffic else None},
+                "mk": {"bound": "hbm", "achieved": ALGO_BYTES_PER_PAIR * extra["mk_pairs_per_s_f32out_device_algebra"] / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                       "frac": extra["mk_frac_hbm_peak"], "bytes_per_pair": ALGO_BYTES_PER_PAIR, "pairs_per_s": extra["mk_pairs_per_s_f32out_device_algebra"],
+                       "bytes_note": "target + reference read by the moments sweep, target re-read and the result written by the affine sweep are 4 "
+                                     "planes moved for SURVEY 8d's 3; priced on the 3", "traffic": None}}
             # configs[2]: DCMCS3DI forward, random init, 512x512.  The convolutions and the attention run float32 operands as two
             # fp16 pieces with three MFMAs per product (float32-grade accuracy, csrc/conv_ws.hip, conv_split.hip, attention16.hip);
             # rates are quoted in algorithmic (float32) FLOPs, and x3 (MFMA flops issued) against the dense 16-bit peak.
@@ -414,26 +435,61 @@ def main():
             # kernels run on: 6 bf16 MFMAs per float32 product in the convolutions and the q.k scores); `frac` = MFMA-busy from
             # the committed counter profile of the same forward (SQ_VALU_MFMA_BUSY_CYCLES over all kernels of the run, time
             # weighted, profiles/r02_dcmcs3di_1080p_mfma_pmc.json); achieved = issued bf16-MFMA-equivalent work, live.
-            busy = read_stamped(os.path.join(ROOT, "profiles", "r05_dcmcs3di_1080p_mfma_pmc.json")) or {}      # {} unless measured on this tree's sources
-            kdom = [v for k, v in busy.items() if "conv_wino_kernel<1>" in k] or [v for k, v in busy.items() if "conv_wino_kernel" in k]
+            busy = read_stamped(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_dcmcs3di_1080p_mfma_pmc.json")) or {}      # {} unless measured on this tree's sources
+            traf = read_stamped(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_dcmcs3di_1080p_traffic.json")) or {}
+            # the dominant kernel: the ResB convolution with a skip tensor (conv_wino4.hip since round 6; conv_wino.hip with CT_HIP_WINO_FORM=1)
+            kname = "w4::conv_wino4_kernel<1, true>" if os.environ.get("CT_HIP_WINO_FORM", "0") != "1" else "conv_wino_kernel<1, true>"
+            kdom = [v for k, v in busy.items() if kname.split("::")[-1] in k]
+            tk = (traf.get("per_kernel") or {}).get(kname) or {}
+            act = 2 * 64 * H * W * 4                      # one 2-view 64-channel float32 activation: 1.062 GB
+            conv_bytes = 3 * act                          # input + skip read, output written: the convolution's own planes (SURVEY 8d style)
+            # ResB convolutions of a forward: 19 blocks on both views (18 extraction + the matcher's head), 6 on one view (transfer); per
+            # block one convolution moves 2 planes (in, out) and one 3 (in, skip, out)
+            resb_bytes = (19 * 2 + 6 * 1) * 5 * (act // 2)
+            hbm = None
+            if tk.get("avg_duration_us"):
+                hbm = {"dominant_kernel": kname, "avg_launch_us": tk["avg_duration_us"], "share_of_gpu_time_pct": tk.get("share_of_gpu_time_pct"),
+                       "algorithmic_bytes_per_launch": conv_bytes,
+                       "GB/s": conv_bytes / (tk["avg_duration_us"] * 1e-6) / 1e9,
+                       "frac_of_hbm_peak": conv_bytes / (tk["avg_duration_us"] * 1e-6) / HBM_PEAK,
+                       "traffic": tk["read_bytes_mean_per_launch"] + tk["write_bytes_mean_per_launch"],
+                       "traffic_over_algorithmic": (tk["read_bytes_mean_per_launch"] + tk["write_bytes_mean_per_launch"]) / conv_bytes,
+                       "source": "profiles/%s_dcmcs3di_1080p_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (gfx950 correction applied) + the "
+                                 "kernel-trace statistics of the same forward, build with source stamp %s (not live)" % (PROFILE_ROUND, source_stamp())}
             roof_cnn = {"bound": "mfma", "workload": "dcmcs3di forward, random init, 1 pair of 1920x1080, float32 I/O",
                         "dtype": "16-bit MFMA pipe (float32 operands as 2 fp16 pieces / 3 MFMAs per product in the convolutions and the "
                                  "attention), f32 accumulate",
                         "achieved": mfma_per_flop * flop2 * dc2 / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                         "frac_flops": mfma_per_flop * flop2 * dc2 / 2.5e15,
                         "frac": busy.get("_all_kernels", {}).get("mfma_busy_frac_time_weighted"),
-                        "frac_source": ("profiles/r05_dcmcs3di_1080p_mfma_pmc.json: ONE rocprofv3 --pmc run of the same forward on a build with source "
+                        "frac_source": ("profiles/" + PROFILE_ROUND + "_dcmcs3di_1080p_mfma_pmc.json: ONE rocprofv3 --pmc run of the same forward on a build with source "
                                         "stamp %s (not live)" % source_stamp()) if busy else
                                        "no PMC profile of this build under profiles/ (source stamp %s): frac is null, never a stale number" % source_stamp(),
                         "forward": t1080,
                         "frac_definition": "MFMA-busy: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), time-weighted over every "
                                            "kernel of the forward",
-                        "dominant_kernel": "conv_wino_kernel<1>",
+                        "dominant_kernel": kname,
                         "dominant_kernel_mfma_busy": kdom[0].get("mfma_busy_frac") if kdom else None,
-                        "frac_note": "MFMA-busy is not comparable with rounds 2-4: as Winograd F(2x2,3x3) the ResB convolutions (73 % of the "
+                        # which roof, and how far: the forward is NOT near the matrix roof and cannot be as an unfused
+                        # float32 design -- its ceiling is HBM
+                        "which_roof": "neither yet: with float32 activations in HBM every ResB convolution streams 2-3 activation planes, so the "
+                                      "unfused design is capped by HBM long before the matrix pipe (ceiling_pairs_per_s_unfused_f32); the dominant "
+                                      "kernel runs at hbm_frac_dominant_kernel of the HBM peak on its own planes and is itself bound by the "
+                                      "issue of one wave per SIMD (vector + LDS + memory instructions ~4000 of ~7000 cycles per 2-row step, "
+                                      "the rest stalls; profiles/" + PROFILE_ROUND + "_conv_wino.txt, DESIGN.md 4.4)",
+                        "hbm_dominant_kernel": hbm,
+                        "hbm_frac_dominant_kernel": hbm["frac_of_hbm_peak"] if hbm else None,
+                        "traffic": hbm["traffic"] if hbm else None,
+                        "ceiling_pairs_per_s_unfused_f32": {"resb_activation_bytes_per_pair": resb_bytes,
+                                                            "at_hbm_peak_8.0_TB/s": HBM_PEAK / resb_bytes,
+                                                            "at_the_5.5_TB/s_a_copy_streams_on_this_chip": 5.5e12 / resb_bytes,
+                                                            "note": "the 50 ResB convolutions alone (19 blocks on two views, 6 on one; 2 + 3 planes "
+                                                                    "per block), before attention / first / last layers: no unfused float32 "
+                                                                    "forward exceeds this; north_star's 0.40 MFMA needs the hidden rows of a "
+                                                                    "block to stay on the CU (DESIGN.md 7)"},
+                        "frac_note": "MFMA-busy is not comparable with rounds 2-4: as Winograd F(2x2,3x3) the ResB convolutions (70 % of the "
                                      "forward) issue 2.25x fewer matrix instructions per output than the direct kernel did (busy 0.40 at "
-                                     "1.0 ms per 2-view conv then, 0.18 at 0.83 ms now, at 2.24 instead of 1.92 GHz: the direct form ran "
-                                     "into the chip's power limit).  pairs_per_s is the figure to compare",
+                                     "1.0 ms per 2-view conv then).  pairs_per_s is the figure to compare",
                         "pairs_per_s": dc2, "algorithmic_f32_tflops": flop2 * dc2 / 1e12,
                         "note": "achieved = MFMA flops issued, priced at the dominant convolutions' rate: 3 products of fp16 pieces per float32 "
                                 "product and 2.25x fewer multiplications as Winograd F(2x2,3x3) = 1.33 per algorithmic flop (the attention and "
@@ -478,7 +534,7 @@ def main():
             # (no whole-forward number for the smooth case: a random-weight matcher emits noise flows for ANY pair -- translated
             # copies by 3 .. 32 px still give a flow std of 130 px, round 5 -- and scaling refine.* down does not change the flow that
             # ENTERS the refinement)
-            gmp = read_stamped(os.path.join(ROOT, "profiles", "r05_gmflow_960x540_mfma_pmc.json"))
+            gmp = read_stamped(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_gmflow_960x540_mfma_pmc.json"))
             extra["gmflow_960x540_mfma_busy_time_weighted"] = gmp.get("_all_kernels", {}).get("mfma_busy_frac_time_weighted") if gmp else None
             if gmp:
                 extra["gmflow_960x540_mfma_busy_note"] = ("MFMA-busy is not comparable across arithmetic forms: the fp16 two-piece kernels issue "

@@ -7,7 +7,7 @@ import csv, glob, json, os, shutil, subprocess, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r05"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r06"
 SRC = os.path.join(ROOT, "gpurun_out", "prof_" + ROUND)
 DST = os.path.join(ROOT, "profiles")
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -140,3 +140,56 @@ if pp:
         o["per_kernel"][k] = e
     json.dump(o, open(os.path.join(DST, ROUND + "_reinhard_persist_traffic.json"), "w"), indent=1)
     print("wrote", ROUND + "_reinhard_persist_traffic.json")
+
+# ---- CNN forwards: HBM bytes per launch of every kernel (round 6; same gfx950 correction), DCMCS3DI 1080p and GMFlow 960x540
+for tag, name in (("dc1080", "dcmcs3di_1080p"), ("gm960", "gmflow_960x540")):
+    per = defaultdict(dict)
+    n = {}
+    for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+        sub = tag + "_" + cname
+        f = newest(sub, "*counter_collection.csv") if os.path.isdir(os.path.join(SRC, sub)) else None
+        if f:
+            agg = defaultdict(lambda: [0.0, 0])
+            for row in csv.DictReader(open(f)):
+                if row["Counter_Name"] == cname:
+                    a = agg[row["Kernel_Name"]]
+                    a[0] += float(row["Counter_Value"]); a[1] += 1
+            for k, (tot, cnt) in agg.items():
+                per[k][cname] = tot / cnt
+                n[k] = cnt
+    if per:
+        o = {**STAMPS, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over tools/bench_%s (two timed forwards + warm-up; per-launch means)"
+                                 % ("dcmcs3di.py 1080 1920 2" if tag == "dc1080" else "gmflow.py 540 960 2"),
+             "correction": out["correction"], "per_kernel": {}}
+        tot_r = tot_w = 0.0
+        for k, d in per.items():
+            if "FETCH_SIZE" in d and "WRITE_SIZE" in d and "ct::" in k:
+                short = k.split("ct::")[-1].split("(")[0]
+                r, w = 2 * d["FETCH_SIZE"] * 1024, d["WRITE_SIZE"] * 1024
+                o["per_kernel"][short] = {"launches_in_run": n[k], "read_bytes_mean_per_launch": int(r), "write_bytes_mean_per_launch": int(w)}
+                tot_r += r * n[k]; tot_w += w * n[k]
+        # average launch duration of the same kernels from the kernel-trace statistics of the (separate, counter-free) stats run
+        sf = newest("trace_" + tag, "*kernel_stats.csv")
+        if sf:
+            for row in csv.DictReader(open(sf)):
+                short = row["Name"].split("ct::")[-1].split("(")[0]
+                if "ct::" in row["Name"] and short in o["per_kernel"]:
+                    o["per_kernel"][short]["avg_duration_us"] = float(row["AverageNs"]) / 1e3
+                    o["per_kernel"][short]["share_of_gpu_time_pct"] = float(row["Percentage"])
+        o["all_ct_kernels_read_bytes_in_run"], o["all_ct_kernels_write_bytes_in_run"] = int(tot_r), int(tot_w)
+        json.dump(o, open(os.path.join(DST, ROUND + "_" + name + "_traffic.json"), "w"), indent=1, sort_keys=True)
+        print("wrote", ROUND + "_" + name + "_traffic.json")
+
+# ---- the ResB convolution alone: both Winograd kernels (times, error, stall counters per step)
+p = os.path.join(SRC, "conv_wino_bench.txt")
+if os.path.exists(p):
+    lines = ["source stamp " + STAMP, "== tools/bench_conv_ws.py 2 64 64 1080 1920 1.0, both Winograd kernels on one box"]
+    lines += [l.rstrip() for l in open(p) if "amdgpu.ids" not in l]
+    lines.append("== tools/pmc_conv_wino.sh: SQ / TCC counters of the same launches (per-launch means; SQ_WAIT_* / SQ_ACTIVE_* in quad-cycles summed over the waves)")
+    for f in sorted(glob.glob(os.path.join(SRC, "form?_?.json"))):
+        j = json.load(open(f))
+        for k, v in j.items():
+            if isinstance(v, dict) and "dispatches" in v:
+                lines.append("%s  %s  %s" % (os.path.basename(f), k[:64], json.dumps({a: round(b, 1) for a, b in sorted(v.items()) if a != "dispatches"})))
+    open(os.path.join(DST, ROUND + "_conv_wino.txt"), "w").write("\n".join(lines) + "\n")
+    print("wrote", ROUND + "_conv_wino.txt")

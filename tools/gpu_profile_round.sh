@@ -1,10 +1,10 @@
 #!/bin/bash
-# GPU box (through gpurun): profiles of one round (ROUND=r05 by default).  Kernel-trace stats of the default bench command, separate PMC passes for HBM
+# GPU box (through gpurun): profiles of one round (ROUND=r06 by default).  Kernel-trace stats of the default bench command, separate PMC passes for HBM
 # traffic / instruction counts of the Reinhard kernels, ONE MFMA-busy run per CNN forward (summarised here, on the box, where only
 # this call's files exist), IDT stats + traffic.  Everything carries the source stamp of the build it ran (tools/stamp.py).
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 OUT=$ROOT/gpurun_out/prof_$ROUND
 rm -rf $OUT; mkdir -p $OUT
 python3 $ROOT/tools/stamp.py > $OUT/source_stamp.txt
@@ -30,6 +30,17 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_i
 for pass in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/idt_$pass -- python3 $ROOT/tools/bench_idt.py > /dev/null 2> $OUT/idt_$pass.err
 done
+# HBM traffic of the CNN kernels (round 6): the same two forwards, FETCH_SIZE and WRITE_SIZE in separate passes
+for pass in FETCH_SIZE WRITE_SIZE; do
+  timeout 400 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/dc1080_$pass -- python3 $ROOT/tools/bench_dcmcs3di.py 1080 1920 2 > /dev/null 2> $OUT/dc1080_$pass.err
+  timeout 400 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/gm960_$pass -- python3 $ROOT/tools/bench_gmflow.py 540 960 2 > /dev/null 2> $OUT/gm960_$pass.err
+done
+find $OUT/dc1080_FETCH_SIZE $OUT/dc1080_WRITE_SIZE $OUT/gm960_FETCH_SIZE $OUT/gm960_WRITE_SIZE -name "*kernel_trace.csv" -delete
+# the ResB convolution alone: both Winograd kernels on one box (times + error against float64), stall counters, phase stamps
+{ for f in 0 1; do echo "== CT_HIP_WINO_FORM=$f (0 = conv_wino4.hip, 1 = conv_wino.hip)"; CT_HIP_WINO_FORM=$f CT_HIP_CONV_WINO=1 python3 $ROOT/tools/bench_conv_ws.py 2 64 64 1080 1920 1.0; done; } > $OUT/conv_wino_bench.txt 2>&1
+bash $ROOT/tools/pmc_conv_wino.sh 0 1 > $OUT/conv_wino_pmc.txt 2>&1
+cp $ROOT/gpurun_out/pmc_conv_wino/*.json $OUT/ 2>/dev/null
+cd /tmp
 cd $ROOT
 # the MFMA-busy summaries are made HERE: this box holds exactly one run per directory
 python3 tools/summarize_pmc.py $OUT/mfma_dc1080 ct:: _all > $OUT/dcmcs3di_1080p_mfma_pmc.json 2> $OUT/summ_dc.err
