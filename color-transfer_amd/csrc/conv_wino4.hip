@@ -347,9 +347,15 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wino4_kernel(ConvArgs a, int
     cx.mr0 = reinterpret_cast<const float *>(vimg) + (mh * 4 + wave) * 64 + 16 * cqd + 2 * tp;
     unsigned int touch = 0;             // destination of the prefetch loads (never read; kept live so that nothing else gets the register)
 
+    // Work split: equal row segments per (output group, image), strips of a segment dealt to the workgroups of ONE XCD (blockIdx % 8):
+    // neighbouring strips and their halo columns meet in one L2, and -- what matters more -- the workgroups of the chip walk down the
+    // SAME rows at the same time, so HBM sees long runs of each channel row.  (Tried, round 6: one sequence of all steps cut into 256
+    // equal ranges, every workgroup 253 steps instead of 270 for most: the launches without a skip tensor gained 3 %, those with one
+    // went from 7400 to 10050 cycles per step -- three streams at 256 unrelated rows; profiles/r06_conv_wino4_ablations.txt.)
     const int n_bands = n_items / n_strips;
     const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
     const int bands_per_xcd = (n_bands + 7) >> 3;
+    int cur_grp = -1;
     for (int li = wg_in_xcd; li < bands_per_xcd * n_strips; li += wgs_per_xcd) {         // XCD-aware order: see conv_ws.hip
         const int sx = li % n_strips;
         int t = (li / n_strips) * 8 + xcd;
@@ -357,8 +363,10 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wino4_kernel(ConvArgs a, int
         const int sy = t % n_seg; t /= n_seg;
         const int nimg = t % a.n_images; const int grp = t / a.n_images;
         // the wave's 64 A fragments, straight into the accumulation registers (global_load writes a[] on gfx950; the compiler's own
-        // route is 256 VGPRs of loads and as many moves).  Once per item: 64 KB per workgroup from L2 against a few hundred steps.
-        {
+        // route is 256 VGPRs of loads and as many moves).  64 KB per workgroup from L2, when the output group changes (once per launch
+        // for cout <= 64).
+        if (grp != cur_grp) {
+            cur_grp = grp;
             const u32x4 *wg = wp16 + ((size_t)grp * 16 + 4 * wave) * 1024 + lane;          // + ((j 4 + mb) 2 + kc) 2 + pc) 64
 #pragma unroll
             for (int j = 0; j < 4; ++j)
