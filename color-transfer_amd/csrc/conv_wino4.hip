@@ -164,7 +164,7 @@ struct St {
     u32x4 wr[4][4][2][2];          // [own position j][cout block][cin chunk][piece]: A fragments, accumulation registers
     float P[2][2][2][2][4];        // input patches [set = pair % 2][role][channel of the pair][row of the pair][column]
     f32x4 acc[4][2];               // [j][cout block of the pass]
-    u32x4 bq[2][2];                // B fragments [cin chunk][piece] of the position in flight
+    u32x4 bq[2][2][2];             // B fragments [position % 2][cin chunk][piece]: one position in use, the next one landing
     float w[2][4][4], v[2][4][4];  // B^T d, (B^T d) B of the role in flight
     float d1c[2][4], w0b[2][4];    // role 1: copy of patch row 1, row 0 of B^T d taken early (see make_prog_x)
     unsigned int hw[16], lw[16];
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wino4_kernel(ConvArgs a, int
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
-                for (int pc = 0; pc < 2; ++pc) st.bq[kc][pc] = frag[(kc * 2 + pc) * 64];
+                for (int pc = 0; pc < 2; ++pc) st.bq[0][kc][pc] = frag[(kc * 2 + pc) * 64];
         };
         // MFMA number Q of a pass (cout blocks 2 PASS, 2 PASS + 1) over V image IMG, with the fragment reads that keep it fed
         auto mfma = [&](auto pass_c, auto img_c, auto q_c) {
@@ -521,12 +521,11 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wino4_kernel(ConvArgs a, int
             constexpr int j = Q / 12, q = Q % 12, kc = q / 6, pr = (q % 6) / 2, ml = q % 2;
             constexpr int pw = pr == 0 ? 1 : 0, pv = pr == 1 ? 1 : 0;            // small terms first: lo x hi, hi x lo, hi x hi
             const u32x4 *frag = reinterpret_cast<const u32x4 *>(vimg + IMG * kVWords) + (4 * wave) * 256 + lane;   // + ((j 2 + kc) 2 + piece) 64
-            if constexpr (q < 2) W4_MFMA0(st.acc[j][ml], st.wr[j][2 * PASS + ml][kc][pw], st.bq[kc][pv]);
-            else W4_MFMA(st.acc[j][ml], st.wr[j][2 * PASS + ml][kc][pw], st.bq[kc][pv]);
-            // the next position's fragments into the registers their predecessors have just left (cin chunk 0 after q = 5, chunk 1
-            // after q = 11, i.e. in the first slices of the next position), one read per slice
-            if constexpr (j < 3 && (q == 6 || q == 7)) st.bq[0][q - 6] = frag[(((j + 1) * 2 + 0) * 2 + (q - 6)) * 64];
-            if constexpr (j > 0 && (q == 0 || q == 1)) st.bq[1][q] = frag[((j * 2 + 1) * 2 + q) * 64];
+            if constexpr (q < 2) W4_MFMA0(st.acc[j][ml], st.wr[j][2 * PASS + ml][kc][pw], st.bq[j & 1][kc][pv]);
+            else W4_MFMA(st.acc[j][ml], st.wr[j][2 * PASS + ml][kc][pw], st.bq[j & 1][kc][pv]);
+            // the next position's four fragments into the other register set, one read per slice, a whole position (12 slices) ahead of
+            // their first use: the slices of phase Y are shorter than an LDS round trip / 6 (round 6: 16 registers more, fewer waits)
+            if constexpr (j < 3 && q < 4) st.bq[(j + 1) & 1][q >> 1][q & 1] = frag[(((j + 1) * 2 + (q >> 1)) * 2 + (q & 1)) * 64];
         };
 
         const int steps = (rows + 1) >> 1;
