@@ -437,12 +437,15 @@ def main():
             # weighted, profiles/r02_dcmcs3di_1080p_mfma_pmc.json); achieved = issued bf16-MFMA-equivalent work, live.
             busy = read_stamped(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_dcmcs3di_1080p_mfma_pmc.json")) or {}      # {} unless measured on this tree's sources
             traf = read_stamped(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_dcmcs3di_1080p_traffic.json")) or {}
-            # the dominant kernel: the ResB convolution with a skip tensor (conv_wino4.hip since round 6; conv_wino.hip with CT_HIP_WINO_FORM=1)
-            kname = "w4::conv_wino4_kernel<1, true>" if os.environ.get("CT_HIP_WINO_FORM", "0") != "1" else "conv_wino_kernel<1, true>"
+            # the dominant kernel: the second convolution of a ResB (no activation, skip tensor; reference pasmnet/backbone.py:8-15) --
+            # conv_wino4.hip since round 6, conv_wino.hip with CT_HIP_WINO_FORM=1
+            kname = "w4::conv_wino4_kernel<0, true>" if os.environ.get("CT_HIP_WINO_FORM", "0") != "1" else "conv_wino_kernel<0, true>"
             kdom = [v for k, v in busy.items() if kname.split("::")[-1] in k]
             tk = (traf.get("per_kernel") or {}).get(kname) or {}
             act = 2 * 64 * H * W * 4                      # one 2-view 64-channel float32 activation: 1.062 GB
-            conv_bytes = 3 * act                          # input + skip read, output written: the convolution's own planes (SURVEY 8d style)
+            # input + skip read, output written = the convolution's own three planes; the profile's per-launch means run over the
+            # forward's 25 such launches: 19 on both views, 6 (the transfer blocks) on one
+            conv_bytes = 3 * act * (19 * 2 + 6 * 1) // (25 * 2)
             # ResB convolutions of a forward: 19 blocks on both views (18 extraction + the matcher's head), 6 on one view (transfer); per
             # block one convolution moves 2 planes (in, out) and one 3 (in, skip, out)
             resb_bytes = (19 * 2 + 6 * 1) * 5 * (act // 2)
@@ -450,6 +453,7 @@ def main():
             if tk.get("avg_duration_us"):
                 hbm = {"dominant_kernel": kname, "avg_launch_us": tk["avg_duration_us"], "share_of_gpu_time_pct": tk.get("share_of_gpu_time_pct"),
                        "algorithmic_bytes_per_launch": conv_bytes,
+                       "algorithmic_bytes_note": "mean over the forward's 25 launches of this kernel (19 x 3.185 GB on two views, 6 x 1.593 GB on one)",
                        "GB/s": conv_bytes / (tk["avg_duration_us"] * 1e-6) / 1e9,
                        "frac_of_hbm_peak": conv_bytes / (tk["avg_duration_us"] * 1e-6) / HBM_PEAK,
                        "traffic": tk["read_bytes_mean_per_launch"] + tk["write_bytes_mean_per_launch"],

@@ -120,6 +120,8 @@ def main(argv=None, timing=None):
                     n += len(ids)
 
             if timing is not None and li == 0:
+                if hasattr(frames, "prepare"):
+                    frames.prepare(mine)                        # the synthetic frames themselves: made before the clock starts
                 run(mine[:3 * frames.group])                    # initialisation, not part of the measurement
                 fence()
                 import time

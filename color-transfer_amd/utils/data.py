@@ -232,6 +232,13 @@ class SyntheticStereoVideoU8:
         group of a rank got the same chunk) -- a function of the frame index only, not of rank or world size"""
         return ((int(first_frame) * 2654435761) >> 9) % self.pool
 
+    def prepare(self, indices):
+        """generate (and pin) every pool chunk the groups of `indices` will take -- a caller that times its loop does this first:
+        generating frames on the host would measure the host (class docstring)"""
+        idx = list(indices)
+        for c in range(0, len(idx), self.group):
+            self._chunk(self._pool_index(idx[c]))
+
     def host_chunk(self, first_frame):
         """the pinned chunk of the group of frames that starts at `first_frame`.  Synthetic data: a group's CONTENT is defined by its
         first frame (chunk _pool_index(first_frame), slots 0..group-1 in order), so per-frame tables depend on how frames are

@@ -136,5 +136,7 @@ def test_synthetic_video_pool_cycles_for_every_stride():
     c = ds.host_chunk(64)
     assert c.shape == (3, 8, 4, 6, 3) and c.dtype == torch.uint8
     assert sum(x is not None for x in ds._chunks) == 1                    # only what was touched
+    ds.prepare(range(0, 1000))                                            # a timed caller makes every chunk of its groups first
+    assert all(x is not None for x in ds._chunks)
     f = ds[64]
     assert torch.equal(f["target"], c[0, 0].permute(2, 0, 1).float() / 255) and torch.equal(f["gt"], c[2, 0].permute(2, 0, 1).float() / 255)

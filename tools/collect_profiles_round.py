@@ -141,6 +141,12 @@ if pp:
     json.dump(o, open(os.path.join(DST, ROUND + "_reinhard_persist_traffic.json"), "w"), indent=1)
     print("wrote", ROUND + "_reinhard_persist_traffic.json")
 
+def kernel_short(name):
+    """'void ct::w4::conv_wino4_kernel<1, true>(ct::ConvArgs, int, ...)' -> 'w4::conv_wino4_kernel<1, true>' (the argument list also holds 'ct::')"""
+    head = name.split("(")[0].replace("void ", "").strip()
+    return head[4:] if head.startswith("ct::") else head
+
+
 # ---- CNN forwards: HBM bytes per launch of every kernel (round 6; same gfx950 correction), DCMCS3DI 1080p and GMFlow 960x540
 for tag, name in (("dc1080", "dcmcs3di_1080p"), ("gm960", "gmflow_960x540")):
     per = defaultdict(dict)
@@ -164,7 +170,7 @@ for tag, name in (("dc1080", "dcmcs3di_1080p"), ("gm960", "gmflow_960x540")):
         tot_r = tot_w = 0.0
         for k, d in per.items():
             if "FETCH_SIZE" in d and "WRITE_SIZE" in d and "ct::" in k:
-                short = k.split("ct::")[-1].split("(")[0]
+                short = kernel_short(k)
                 r, w = 2 * d["FETCH_SIZE"] * 1024, d["WRITE_SIZE"] * 1024
                 o["per_kernel"][short] = {"launches_in_run": n[k], "read_bytes_mean_per_launch": int(r), "write_bytes_mean_per_launch": int(w)}
                 tot_r += r * n[k]; tot_w += w * n[k]
@@ -172,7 +178,7 @@ for tag, name in (("dc1080", "dcmcs3di_1080p"), ("gm960", "gmflow_960x540")):
         sf = newest("trace_" + tag, "*kernel_stats.csv")
         if sf:
             for row in csv.DictReader(open(sf)):
-                short = row["Name"].split("ct::")[-1].split("(")[0]
+                short = kernel_short(row["Name"])
                 if "ct::" in row["Name"] and short in o["per_kernel"]:
                     o["per_kernel"][short]["avg_duration_us"] = float(row["AverageNs"]) / 1e3
                     o["per_kernel"][short]["share_of_gpu_time_pct"] = float(row["Percentage"])
