@@ -81,6 +81,20 @@ __device__ __forceinline__ float pow2i_h(int e) { return __uint_as_float((unsign
 
 constexpr int kSsRowH(int C) { return 2 * C + 16; }   // bytes per LDS row of a tile image: 16-byte fragment reads are conflict free
 
+// XCD-aware workgroup order (round 6).  Workgroups are dealt to the 8 XCDs round-robin by their linear id, and an XCD's L2 is its own:
+// with the plain (x, y) order the ~15 query tiles of one token row land on all eight XCDs and each of them fetches that row's keys and
+// values from HBM -- profiles/r06_dcmcs3di_1080p_traffic.json: 11.4 GB read per launch of the 1080p parallax attention whose inputs
+// are 2.4 GB.  Remapped, the tiles an XCD receives one after the other are the tiles of consecutive rows: lin -> (lin % 8) * (n / 8) +
+// lin / 8 on the first n = 8 * (total / 8) workgroups (a bijection), identity on the rest.  Returns the (x, y) this workgroup acts as.
+__device__ __forceinline__ void xcd_order(int &bx, int &by) {
+    bx = blockIdx.x; by = blockIdx.y;
+    if (gridDim.z != 1) return;
+    const unsigned int gx = gridDim.x, total = gx * gridDim.y, lin = by * gx + bx, full = total & ~7u;
+    if (lin >= full) return;
+    const unsigned int vid = (lin & 7u) * (full >> 3) + (lin >> 3);
+    bx = (int)(vid % gx); by = (int)(vid / gx);
+}
+
 template <int C, int CV, bool MAP>
 __global__ __launch_bounds__(256, 2) void attention16_tokens_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                                     const float *__restrict__ v, const int *__restrict__ region,
@@ -103,8 +117,9 @@ __global__ __launch_bounds__(256, 2) void attention16_tokens_kernel(const float 
     __shared__ __attribute__((aligned(16))) float Mx[8];    // [wave][K, V] tile maxima of the tile about to be staged
     __shared__ float Gs[2];                                 // {2^-e, 2^e} of the staged K tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, hl = lane >> 5;
-    const int b = blockIdx.y;
-    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    int bxo, b;
+    xcd_order(bxo, b);
+    const int q0 = (bxo * 4 + wave) * 32;
     const size_t tb = (size_t)b * L;
     const int qi = q0 + nl;
     const bool qlive = qi < L;
@@ -427,8 +442,9 @@ __global__ __launch_bounds__(256, 2) void attention16_colsum_kernel(const float 
     __shared__ __attribute__((aligned(16))) float Mx[4];
     __shared__ float Gs[1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, hl = lane >> 5;
-    const int b = blockIdx.y;
-    const int j0 = (blockIdx.x * 4 + wave) * 32;
+    int bxo, b;
+    xcd_order(bxo, b);
+    const int j0 = (bxo * 4 + wave) * 32;
     const size_t tb = (size_t)b * L;
     const int kj = j0 + nl;
     uint4 kf[C / 16][2];                            // B fragments: this lane's key row (a workgroup's surplus waves clamp)
