@@ -897,12 +897,28 @@ def conv2d(x, wp, bias, cout, ksize, act=0, residual=None, clamp=False, out=None
     return out
 
 
-def conv2d_rows(x, wp, bias, cout, ksize, act=0, out=None, c0=0, channels=None):
+def conv2d_rows(x, wp, bias, cout, ksize, act=0, out=None, c0=0, channels=None, raw=None):
     """conv2d whose result is written as token rows: out[n*H + y, x, c0 + co] of a [N*H, W, channels] tensor (the layout the
     streaming attention reads), so the NCHW tensor and its transpose are never made.  Returns None when the split kernel cannot
-    take the convolution (exact mode, W % 4): the caller then runs conv2d + the transpose."""
+    take the convolution (exact mode, W % 4): the caller then runs conv2d + the transpose.
+    raw = (Conv2d weight, bias or None): with it a 1x1 convolution of 64 input channels takes the streaming float32 kernel
+    ct_conv1x1_rows_f32 (csrc/conv1x1_rows.hip) in every convolution mode."""
     split = getattr(wp, "_ct_split", None)
     n, cin, h, w = x.shape
+    if (raw is not None and ksize == 1 and cin == 64 and cout <= 64 and cout % 4 == 0 and x.is_cuda and x.dtype == torch.float32 and
+            x.stride(3) == 1 and x.stride(2) == w and x.stride(1) == h * w and act <= 4):
+        _check_device(x)
+        channels = int(channels if channels is not None else (out.shape[2] if out is not None else cout))
+        if out is None:
+            out = torch.empty((n * h, w, channels), dtype=torch.float32, device=x.device)
+        if (out.shape != (n * h, w, channels) or not out.is_contiguous() or out.dtype != torch.float32 or out.device != x.device or
+                channels % 4 or c0 % 4 or c0 + cout > channels):
+            raise CtHipError("conv2d_rows: out must be a contiguous float32 [N*H, W, channels] tensor, channels / c0 / cout multiples of 4")
+        wt = raw[0].detach().reshape(cout, 64).contiguous().float()
+        bs = raw[1].detach().contiguous().float() if raw[1] is not None else torch.zeros(cout, dtype=torch.float32, device=x.device)
+        check(lib().ct_conv1x1_rows_f32(_ptr(x), _ptr(wt), _ptr(bs), _ptr(out), n, cin, cout, h, w, _nchw_bstride(x), channels, int(c0),
+                                        int(act), _stream()))
+        return out
     if split is None or not x.is_cuda or x.dtype != torch.float32 or not _split_ok(x, None, None, ksize, ksize, 1, ksize // 2, ksize // 2):
         return None
     _check_device(x)
@@ -965,6 +981,7 @@ SIGNATURES.update({
     "ct_conv3x3_ws16_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p] + [_c_int] * 5 + [_c_ll, _c_ll, _c_ll, _c_int, _c_int, _c_p]),
     "ct_conv3x3_wino16_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p] + [_c_int] * 5 + [_c_ll, _c_ll, _c_ll, _c_int, _c_int, _c_p]),
     "ct_set_conv_wino_form": (_c_int, [_c_int]),
+    "ct_conv1x1_rows_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 5 + [_c_ll, _c_int, _c_int, _c_int, _c_p]),
     "ct_instance_norm_workspace_bytes": (ctypes.c_size_t, [_c_int]),
     "ct_instance_norm_f32": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_f, _c_int, _c_p, ctypes.c_size_t, _c_p]),
     "ct_eltwise_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_f, _c_p]),

@@ -35,7 +35,8 @@ def conv_forward_rows(conv, x, out=None, c0=0, channels=None):
     """conv_forward writing token rows [N*H, W, channels] (channels c0 .. c0 + cout) for the streaming attention: the split
     kernel's epilogue stores that layout directly; otherwise (exact mode, W % 4) the NCHW result is transposed"""
     wp, bias = packed_weights(conv)
-    rows = ct_hip.conv2d_rows(x, wp, bias, conv.out_channels, conv.kernel_size[0], out=out, c0=c0, channels=channels)
+    rows = ct_hip.conv2d_rows(x, wp, bias, conv.out_channels, conv.kernel_size[0], out=out, c0=c0, channels=channels,
+                              raw=(conv.weight, conv.bias))
     if rows is None:
         n, _, h, w = x.shape
         if out is None:

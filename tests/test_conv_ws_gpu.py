@@ -528,3 +528,30 @@ def test_conv_split_stream_k_graph_replay_and_busy_gpu(hip):
         assert torch.equal(hip.gconv2d(x, wp, bp, cout, (1, 5), 1, (0, 2)), want)
     torch.cuda.synchronize()
     assert hip.conv_stream_k_state() == (0, 0)
+
+
+@pytest.mark.parametrize("cfg", [(2, 64, 9, 64, 64, 0, 0), (1, 64, 5, 100, 96, 32, 1), (3, 32, 4, 36, 32, 0, 0), (1, 4, 3, 8, 8, 4, 2),
+                                 (2, 60, 7, 1920, 64, 0, 0), (1, 64, 1, 4, 128, 64, 3)])
+def test_conv1x1_rows_vs_float64(hip, cfg):
+    """ct_conv1x1_rows_f32 (csrc/conv1x1_rows.hip: the query / key / value 1x1 convolutions in front of the parallax attention as a
+    streaming kernel on the exact-f32 matrix pipe; reference pasmnet/attention.py:39-40,44-45, dcmcs3di.py:58) against the float64
+    convolution: widths that are not multiples of the 32-pixel segment, cout below 32 / 64, rows wider than cout with an offset (the
+    value rows carry RGB behind the 64 channels), every activation, several images; nothing outside the written channels changes."""
+    n, cout, h, w, channels, c0, act = cfg
+    x, wt, b = rnd(n, 64, h, w) * 2, rnd(cout, 64, 1, 1) / 8, rnd(cout)
+    ref = F.conv2d(x.double(), wt.double(), b.double())
+    want = (ref, F.leaky_relu(ref, 0.01), torch.relu(ref), torch.sigmoid(ref))[act].permute(0, 2, 3, 1).reshape(n * h, w, cout)
+    wp, bp = hip.pack_conv_weight(wt.cuda(), b.cuda())
+    out = torch.full((n * h, w, channels), 777.0, device="cuda")
+    got = hip.conv2d_rows(x.cuda(), wp, bp, cout, 1, act=act, out=out, c0=c0, channels=channels, raw=(wt.cuda(), b.cuda()))
+    assert got is out
+    torch.cuda.synchronize()
+    o = out.cpu().double()
+    err = (o[:, :, c0:c0 + cout] - want).abs().max().item()
+    assert err < 2e-6 * max(1.0, ref.abs().max().item()), (cfg, err)
+    assert bool((o[:, :, :c0] == 777.0).all()) and bool((o[:, :, c0 + cout:] == 777.0).all())
+    # a view of a larger batch (the two views of a stereo pair live in one tensor) and no bias
+    big = rnd(n + 1, 64, h, w).cuda()
+    got2 = hip.conv2d_rows(big[1:], wp, bp, cout, 1, out=None, raw=(wt.cuda(), None))
+    want2 = F.conv2d(big[1:].cpu().double(), wt.double()).permute(0, 2, 3, 1).reshape(n * h, w, cout)
+    assert (got2.cpu().double() - want2).abs().max().item() < 2e-6 * max(1.0, want2.abs().max().item())
