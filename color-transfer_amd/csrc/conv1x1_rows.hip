@@ -47,8 +47,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(Rows1x1Args a) {
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb) {
         const int co = 32 * mb + n;
+        const f32x4r *wrow = reinterpret_cast<const f32x4r *>(a.w + (size_t)min(co, a.cout - 1) * 64);      // the lane's weight row, 16 bytes at a time
 #pragma unroll
-        for (int st = 0; st < 32; ++st) wa[mb][st] = co < a.cout ? a.w[(size_t)co * 64 + 2 * st + hl] : 0.f;
+        for (int q = 0; q < 16; ++q) {
+            const f32x4r v = wrow[q];                               // columns 4 q .. 4 q + 3 = K steps 2 q (columns 4 q, 4 q + 1) and 2 q + 1
+            wa[mb][2 * q] = co < a.cout ? (hl ? v[1] : v[0]) : 0.f;
+            wa[mb][2 * q + 1] = co < a.cout ? (hl ? v[3] : v[2]) : 0.f;
+        }
     }
     // the bias of the 4 output channels this lane stores per (mb, g): 32 mb + 8 g + 4 hl + 0..3
     f32x4r bv[NMB][4];
@@ -125,13 +130,13 @@ extern "C" {
 
 // 1x1 convolution 64 -> cout (<= 64, a multiple of 4) with token-row output, exact float32 arithmetic on the float32 matrix pipe.
 // weight: the Conv2d weight itself, float32 [cout][64]; bias [cout]; out_rows: [n h, w, rows_channels], channels rows_c0 .. rows_c0 + cout
-// are written (rows_channels, rows_c0 multiples of 4, 16-byte aligned base).  act as ct_conv2d_split_f32 (0 none .. 4 tanh).
+// are written (rows_channels, rows_c0 multiples of 4; out_rows and weight 16-byte aligned).  act as ct_conv2d_split_f32 (0 none .. 4 tanh).
 int ct_conv1x1_rows_f32(const float *in, const float *weight, const float *bias, float *out_rows, int n, int cin, int cout, int h, int w,
                         long long in_bstride, int rows_channels, int rows_c0, int act, void *stream) {
     if (!in || !weight || !bias || !out_rows || n < 0 || cin != 64 || cout < 1 || cout > 64 || (cout & 3) || h < 0 || w < 0 || act < 0 || act > 4)
         return CT_E_BADARG;
     if (rows_channels < 4 || (rows_channels & 3) || rows_c0 < 0 || (rows_c0 & 3) || rows_c0 + cout > rows_channels) return CT_E_BADARG;
-    if (reinterpret_cast<uintptr_t>(out_rows) & 15) return CT_E_ALIGN;
+    if ((reinterpret_cast<uintptr_t>(out_rows) & 15) || (reinterpret_cast<uintptr_t>(weight) & 15)) return CT_E_ALIGN;
     if (n == 0 || h == 0 || w == 0) return CT_OK;
     const long long tiles_x = (w + 31) / 32, n_tiles = tiles_x * h * n;
     if (n_tiles > 0x7fffffffLL) return CT_E_BADARG;
@@ -140,7 +145,8 @@ int ct_conv1x1_rows_f32(const float *in, const float *weight, const float *bias,
     a.cout = cout; a.H = h; a.W = w; a.tiles_x = (int)tiles_x; a.n_tiles = (int)n_tiles; a.pitch = rows_channels; a.c0 = rows_c0; a.act = act;
     a.in_bstride = in_bstride;
     long long blocks = (n_tiles + 3) / 4;
-    if (blocks > 256 * 8) blocks = 256 * 8;                      // persistent: up to 8 workgroups of 4 waves per CU's worth of tiles in flight
+    if (blocks > 256 * 2) blocks = 256 * 2;                      // persistent: the two workgroups a CU holds (213 registers per lane); a wave's
+                                                                 // prologue fetches the 16 KB of weights, so waves should live long
     if (cout <= 32) hipLaunchKernelGGL(ct::conv1x1_rows_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(ct::conv1x1_rows_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     CT_CHECK_LAUNCH();

@@ -318,7 +318,7 @@ int ct_conv2d_split_rows_f32(const float *in, const void *wp_split, const float 
  * 64 input channels -> cout <= 64 (a multiple of 4), as a STREAMING kernel of its own (csrc/conv1x1_rows.hip; new in ABI 9): exact float32
  * products on the float32 matrix pipe (v_mfma_f32_32x32x2_f32), the 64 x 64 weights in a wave's registers, no LDS, no barrier -- a 1x1
  * convolution is HBM-bound by a factor of two even there.  weight: the Conv2d weight itself, float32 [cout][64]; bias [cout];
- * out_rows / rows_channels / rows_c0 / act (0 .. 4) as above; out_rows 16-byte aligned. */
+ * out_rows / rows_channels / rows_c0 / act (0 .. 4) as above; out_rows and weight 16-byte aligned. */
 int ct_conv1x1_rows_f32(const float *in, const float *weight, const float *bias, float *out_rows, int n, int cin, int cout, int h, int w,
                         long long in_bstride, int rows_channels, int rows_c0, int act, void *stream);
 
