@@ -43,7 +43,8 @@ constexpr size_t kLds = 2 * (size_t)kVWords * 4 + 16384 + 128;    // two images 
 // (weight ~ instructions), one slice behind each MFMA -------------------------------------------------------------------------------
 enum : int { OP_W, OP_V, OP_H0, OP_H1, OP_L0, OP_L1, OP_SH, OP_SL, OP_CP, OP_LD, OP_SK,   // input transform of step s + 1; OP_SK: skip-row request
              OP_TAIL,                                                              // M A of cout blocks 0, 1 (accumulators of phase Y)
-             OP_RD, OP_YA, OP_EP, OP_ST };                                         // output side of step s
+             OP_RD, OP_YA, OP_EP, OP_ST,                                           // output side of step s
+             OP_MX, OP_MXF };                                                      // maximum of the landed row pair (4 chains), its reduction
 struct Op { int kind, r, a, b, c, wt; };
 constexpr int kMaxOps = 400;
 struct Prog { Op op[kMaxOps]; int n; int wsum; };
@@ -139,6 +140,7 @@ constexpr Prog make_prog_y() {
     for (int k = 0; k < 2; ++k)
         for (int w = 0; w < 4; ++w)
             for (int b = 0; b < 2; ++b) push(p, OP_RD, k, w, b, 0, 1);
+    // the output side, per cout: A^T (M A), epilogue, stores
     for (int k = 0; k < 2; ++k) {
         for (int a = 0; a < 2; ++a)
             for (int c = 0; c < 4; ++c) push(p, OP_YA, k, a, c, 0, 2);
@@ -147,6 +149,11 @@ constexpr Prog make_prog_y() {
             push(p, OP_ST, k, a, 0, 0, 2);
         }
     }
+    // the maximum of the row pair that landed during phase X, LAST (its loads went out in the first half of phase X and are the
+    // one thing of a step that comes from HBM with nothing to hide behind): four independent chains inside the last MFMA slices
+    // instead of round 6's first form, a serial block of 16 v_max3 + 6 DPP steps in front of the barrier
+    for (int i = 0; i < 16; ++i) push(p, OP_MX, i >> 3, (i >> 2) & 1, (i >> 1) & 1, i & 1, 1);        // (role, channel, row, half)
+    push(p, OP_MXF, 0, 0, 0, 0, 10);
     return p;
 }
 constexpr Prog kProgX0 = make_prog_x(false), kProgX1 = make_prog_x(true), kProgY = make_prog_y(), kProgT0 = make_prog_t(true);
@@ -172,6 +179,7 @@ struct St {
     f32x2 tq[2][4][2];             // phase Y: (M A)[w][b] of two tiles, for the thread's two couts
     float y[2][2][4];              // [k][output row][4 columns]
     f32x4 rq[2][2];                // skip rows [k][output row]
+    float mx4[4];                  // four chains of the landed pair's maximum
 };
 
 #ifndef W4_ABL_NO_MFMA
@@ -191,6 +199,8 @@ struct Ctx {
     unsigned int sto[2];            // byte offset of (cout k, first column) in this group's planes, or 2^31 (out of range)
     float bias[2];
     int act;
+    float *rowmax_w;                // where this wave leaves the landed pair's maximum (set per step)
+    bool lane63;
 };
 
 // one operation of a program.  TP = (index of the transformed step) % 2: patch rows 0, 1 are pair t (set TP), rows 2, 3 pair t + 1
@@ -282,6 +292,19 @@ __device__ __forceinline__ void do_op(St &st, const Ctx &cx, const LoadF &load_r
         else if constexpr (ACTK == 3) v = split_act<true>(v, cx.act);
         if constexpr (HAS_RES) v += st.rq[k][a][c];
         st.y[k][a][c] = v;
+    } else if constexpr (o.kind == OP_MX) {     // pair landed in set TP ^ 1 ... of the step two ahead: the caller passes its set as TP
+        constexpr int e = o.a, row = o.b, half = o.c, idx = ((r * 2 + e) * 2 + row) * 2 + half;
+        const float(&q)[4] = st.P[TP][r][e][row];
+        if constexpr (idx < 4) asm("v_max_f32 %0, |%1|, |%2|" : "=v"(st.mx4[idx & 3]) : "v"(q[2 * half]), "v"(q[2 * half + 1]));
+        else asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(st.mx4[idx & 3]) : "v"(q[2 * half]), "v"(q[2 * half + 1]));
+    } else if constexpr (o.kind == OP_MXF) {
+        float m = fmaxf(fmaxf(st.mx4[0], st.mx4[1]), fmaxf(st.mx4[2], st.mx4[3]));
+        int x = __float_as_int(m);
+#define CT_DPP_MAX(ctrl, rmask) x = max(x, __builtin_amdgcn_update_dpp(0, x, ctrl, rmask, 0xf, false))
+        CT_DPP_MAX(0x111, 0xf); CT_DPP_MAX(0x112, 0xf); CT_DPP_MAX(0x114, 0xf); CT_DPP_MAX(0x118, 0xf);
+        CT_DPP_MAX(0x142, 0xa); CT_DPP_MAX(0x143, 0xc);
+#undef CT_DPP_MAX
+        if (cx.lane63) *cx.rowmax_w = __int_as_float(x);
     } else {                                    // OP_ST: four columns of one output row of one cout
         constexpr int k = o.r, a = o.a;
 #ifdef W4_ABL_NO_ST
@@ -329,6 +352,8 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wino4_kernel(ConvArgs a, int
     Ctx cx;
     const u32x4 *wp16 = reinterpret_cast<const u32x4 *>(a.wp);
     cx.act = a.act;
+    cx.lane63 = (threadIdx.x & 63) == 63;
+    cx.rowmax_w = nullptr;
 
     // T role r of a thread: tile tt, channel pair 16 r + 4 wave + lane / 16  (the wave is the k-group of its words in the B fragment)
     const int tt = lane & 15, cq = lane >> 4;
@@ -440,7 +465,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wino4_kernel(ConvArgs a, int
         };
         // what the landed pair k still needs: zero rows outside the image (uniform), edge columns / missing channels (edge strips), then
         // the maximum of |x| over the pair, per wave, into rowmax[k % 4][wave]
-        auto finish_pair = [&](int k, float (&p)[2][2][2][4]) {
+        auto fix_pair = [&](int k, float (&p)[2][2][2][4]) {
 #pragma unroll
             for (int row = 0; row < 2; ++row) {
                 const int y = row_of(k, row);
@@ -471,6 +496,9 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wino4_kernel(ConvArgs a, int
                         }
                     }
             }
+        };
+        auto finish_pair = [&](int k, float (&p)[2][2][2][4]) {       // prologue form: fix-ups, then the maximum as one block
+            fix_pair(k, p);
             float m = 0.f;
 #pragma unroll
             for (int r = 0; r < 2; ++r)
@@ -600,7 +628,9 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wino4_kernel(ConvArgs a, int
             }
 #endif
             W4_STAMP(2);
+#ifndef W4_ABL_NO_BAR1
             __syncthreads();
+#endif
             W4_STAMP(3);
             // ---------------- phase Y: cout blocks 0, 1 of step s + 1; the output side of step s ----------------
             {
@@ -609,6 +639,8 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wino4_kernel(ConvArgs a, int
                 const unsigned int ro0 = (2 * s < rows) ? (unsigned int)(oy * a.W) * 4u : 0x40000000u;
                 const unsigned int ro1 = (2 * s + 1 < rows) ? (unsigned int)((oy + 1) * a.W) * 4u : 0x40000000u;
                 first_frags(PAR ^ 1);
+                fix_pair(s + 3, st.P[PAR ^ 1]);            // rows outside the image, edge strips: uniform branches, normally nothing
+                cx.rowmax_w = rowmax + ((s + 3) & 3) * 4 + wave;
                 __builtin_amdgcn_sched_barrier(0);
                 for_each_c([&](auto c_c) {
                     constexpr int C = decltype(c_c)::value;
@@ -619,10 +651,9 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wino4_kernel(ConvArgs a, int
                 }, std::make_integer_sequence<int, 48>());
             }
             W4_STAMP(4);
-#ifndef W4_ABL_NO_FIN
-            finish_pair(s + 3, st.P[PAR ^ 1]);
-#endif
+#ifndef W4_ABL_NO_BAR2
             __syncthreads();
+#endif
             W4_STAMP(5);
             W4_STAMPS_END();
         };
