@@ -330,8 +330,10 @@ def test_conv_rows_argument_checks_and_fallback(hip):
 
 
 def test_dcmcs3di_rows_path_equals_transposed_path(hip):
-    """the forward pass with q / k / v written as rows by the convolutions == the one that transposes NCHW q / k / v (bitwise:
-    the same values reach the attention kernels)"""
+    """the forward pass with q / k / v written as rows by the convolutions against the one that transposes NCHW q / k / v.  Until
+    round 5 both came from the same tile kernel and agreed bitwise; since round 6 the rows come from ct_conv1x1_rows_f32 (exact float32
+    products, csrc/conv1x1_rows.hip) and the NCHW tensors from the two-piece tile kernel: the same values to float32 rounding, and the
+    attention outputs with them (the mask away from its 0.1 threshold)."""
     from methods.dcmcs3di import DCMCS3DI
     from pasmnet.backbone import conv_forward
     torch.manual_seed(3)
@@ -346,8 +348,10 @@ def test_dcmcs3di_rows_path_equals_transposed_path(hip):
     q, k = conv_forward(net.matcher.query, head), conv_forward(net.matcher.key, head)
     v = conv_forward(net.matcher.value, fea[1:])
     fw, wrgb, valid, colsum = hip.pam_streaming(q[:1].contiguous(), k[1:].contiguous(), v, right, q[1:].contiguous(), k[:1].contiguous())
-    assert torch.equal(parts["fea_warped"], fw) and torch.equal(parts["warped_rgb"], wrgb)
-    assert torch.equal(parts["colsum_left"], colsum) and torch.equal(parts["valid_left"], valid)
+    for got, want in ((parts["fea_warped"], fw), (parts["warped_rgb"], wrgb), (parts["colsum_left"], colsum)):
+        assert (got - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+    away = (colsum - 0.1).abs() > 1e-4
+    assert torch.equal(parts["valid_left"][away], valid[away])
 
 
 @pytest.mark.parametrize("kh,kw", [(3, 3), (1, 5), (5, 1), (1, 1)])
