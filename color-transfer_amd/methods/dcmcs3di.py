@@ -33,8 +33,12 @@ class DCMCS3DI(torch.nn.Module):
         super().__init__()
         self.hparams = type("HParams", (), dict(extraction_layers=extraction_layers, transfer_layers=transfer_layers,
                                                 channels=channels))()
-        if channels != 64:
-            raise ValueError("the HIP kernels are built for channels=64 (the reference's configs/dcmcs3di.yaml)")
+        # the reference takes any width (dcmcs3di.py:30-51).  64 (configs/dcmcs3di.yaml) runs on the kernels built for it (Winograd ResB
+        # convolutions, streaming attention at any image width); other widths take the generic paths: tile convolutions, and the
+        # LDS-tile attention (images up to ~1000 columns).  The three-source 1x1 convolution of transfer[0] wants channel counts that are
+        # multiples of 16; the attention kernels contract over 64 query / key channels (narrower ones are zero-padded, see forward_parts).
+        if channels % 16 or not 16 <= channels <= 64:
+            raise ValueError("channels must be 16, 32, 48 or 64 (the reference's configs/dcmcs3di.yaml uses 64)")
         # construction order == reference (dcmcs3di.py:41-51): torch.manual_seed(s) gives the same init
         self.extraction = torch.nn.Sequential(torch.nn.Conv2d(3, channels, kernel_size=3, padding=1))
         for _ in range(extraction_layers):
@@ -59,16 +63,25 @@ class DCMCS3DI(torch.nn.Module):
         head = resb_forward(self.matcher.head, fea)                        # attention.py:35-36
         fea_left, fea_right = fea[:B], fea[B:]
         H, W = left.shape[2], left.shape[3]
-        if want_att or want_valid_right:
+        tile_path = want_att or self.hparams.channels != 64      # the streaming kernels are built for 64 channels
+        if tile_path or want_valid_right:
             q = conv_forward(self.matcher.query, head)                     # attention.py:39,44
             k = conv_forward(self.matcher.key, head)                       # attention.py:40,45
-        if want_att:
-            # the [B,H,W,W] maps are wanted: LDS-tile kernels that can write them out
+            c = q.shape[1]
+            if c != 64:
+                # the attention kernels contract over 64 channels and scale the scores by 1 / 64; the reference scales by 1 / c
+                # (attention.py:41): zero channels add nothing to a score, and q * (64 / c) puts the scale right
+                q64, k64 = q.new_zeros((q.shape[0], 64) + tuple(q.shape[2:])), k.new_zeros((k.shape[0], 64) + tuple(k.shape[2:]))
+                q64[:, :c] = q * (64.0 / c)
+                k64[:, :c] = k
+                q, k = q64, k64
+        if tile_path:
+            # the [B,H,W,W] maps are wanted (or the width is not 64): LDS-tile kernels that can write them out
             v = conv_forward(self.matcher.value, fea_right)                # dcmcs3di.py:58
             # right-to-left: Q(left) . K(right)
-            fea_warped, warped_rgb, att_r2l = ct_hip.pam_attend(q[:B], k[B:], v, right, want_att=True)
+            fea_warped, warped_rgb, att_r2l = ct_hip.pam_attend(q[:B].contiguous(), k[B:].contiguous(), v, right, want_att=want_att)
             # left-to-right softmax, column sums -> valid mask of the LEFT view (utils.py:31,34-35)
-            valid_left, colsum_left, att_l2r = ct_hip.pam_valid(q[B:], k[:B], want_att=True)
+            valid_left, colsum_left, att_l2r = ct_hip.pam_valid(q[B:].contiguous(), k[:B].contiguous(), want_att=want_att)
         else:
             # streaming (online-softmax) kernels: no score tile in LDS, any width, K/V rows fetched with 16-byte loads.  They read
             # token rows [B*H, W, C]; the three 1x1 convolutions store that layout from their epilogues (no NCHW q/k/v, no
